@@ -1,0 +1,330 @@
+"""ctypes binding of the CPU ORACLE (oracle/_build/libsc_oracle.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg -- never by the product package (smart-chess-rust_amd/).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "_build", "libsc_oracle.so")
+
+MAX_PLY = 1024
+MAX_MOVES = 256
+
+
+def build(force=False):
+    srcs = [os.path.join(_HERE, f) for f in ("chess.c", "nn.c", "mcts.c", "sc_oracle.h", "sc_oracle_nn.h",
+                                              "sc_oracle_mcts.h", "Makefile")]
+    if not force and os.path.exists(_LIB) and all(os.path.getmtime(_LIB) >= os.path.getmtime(s) for s in srcs):
+        return _LIB
+    subprocess.check_call(["make", "-s", "-C", _HERE])
+    return _LIB
+
+
+class Trace(C.Structure):
+    _fields_ = [
+        ("n_steps", C.c_int),
+        ("moves", C.c_uint16 * MAX_PLY),
+        ("q_root", C.c_float * MAX_PLY),
+        ("child_off", C.c_int * (MAX_PLY + 1)),
+        ("child_move", C.POINTER(C.c_uint16)),
+        ("child_n", C.POINTER(C.c_int32)),
+        ("child_q", C.POINTER(C.c_float)),
+        ("child_uct", C.POINTER(C.c_float)),
+        ("has_outcome", C.c_int),
+        ("termination", C.c_int),
+        ("winner", C.c_int),
+        ("n_sims", C.c_int64),
+        ("n_evals", C.c_int64),
+    ]
+
+
+class SelfplayCfg(C.Structure):
+    _fields_ = [
+        ("rollout_num", C.c_int),
+        ("num_steps", C.c_int),
+        ("cpuct", C.c_float),
+        ("temperature", C.c_float),
+        ("temperature_switch", C.c_int),
+        ("epsilon", C.c_float),
+        ("with_noise", C.c_int),
+        ("faithful", C.c_int),
+        ("seed", C.c_uint64),
+        ("game_id", C.c_uint64),
+        ("outcome_gate", C.c_int),
+    ]
+
+
+EVAL_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_uint16), C.POINTER(C.c_int),
+                      C.POINTER(C.c_float), C.POINTER(C.c_float))
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    build()
+    L = C.CDLL(_LIB)
+    vp, i32, u16, u64 = C.c_void_p, C.c_int, C.c_uint16, C.c_uint64
+    sig = {
+        "orc_state_new": (vp, []),
+        "orc_state_free": (None, [vp]),
+        "orc_state_reset": (None, [vp]),
+        "orc_state_set_fen": (i32, [vp, C.c_char_p]),
+        "orc_state_copy": (None, [vp, vp]),
+        "orc_fen": (i32, [vp, C.c_char_p, i32]),
+        "orc_turn": (i32, [vp]),
+        "orc_ply": (i32, [vp]),
+        "orc_piece_at": (i32, [vp, i32]),
+        "orc_push": (None, [vp, u16]),
+        "orc_pop": (u16, [vp]),
+        "orc_legal_moves": (i32, [vp, C.POINTER(u16)]),
+        "orc_is_check": (i32, [vp]),
+        "orc_perft": (u64, [vp, i32]),
+        "orc_is_repetition": (i32, [vp, i32]),
+        "orc_outcome": (i32, [vp, C.POINTER(i32), C.POINTER(i32)]),
+        "orc_move_uci": (i32, [u16, C.c_char_p]),
+        "orc_move_from_uci": (u16, [C.c_char_p]),
+        "orc_move_index": (i32, [u16, i32]),
+        "orc_encode": (None, [vp, vp, vp]),
+        "orc_net_num_tensors": (i32, [i32]),
+        "orc_net_tensor_shape": (C.c_int64, [i32, i32, i32, C.POINTER(i32), C.POINTER(i32)]),
+        "orc_prng_weight": (C.c_float, [u64, i32, u64, C.c_double, C.c_double]),
+        "orc_net_create": (vp, [i32, i32, u64, i32]),
+        "orc_net_free": (None, [vp]),
+        "orc_net_set_tensor": (i32, [vp, i32, vp, C.c_int64]),
+        "orc_net_get_tensor": (i32, [vp, i32, vp, C.c_int64]),
+        "orc_net_forward": (None, [vp, vp, vp, vp, vp, vp]),
+        "orc_mix64": (u64, [u64]),
+        "orc_pos_hash": (u64, [vp]),
+        "orc_rng": (u64, [u64, u64, u64, u64, u64]),
+        "orc_search_new": (vp, [vp, i32]),
+        "orc_search_free": (None, [vp]),
+        "orc_search_sim": (None, [vp, vp, vp, C.c_float, C.c_float, i32, vp, i32]),
+        "orc_search_num_nodes": (i32, [vp]),
+        "orc_search_num_evals": (C.c_int64, [vp]),
+        "orc_search_dump": (None, [vp, vp, vp, vp, vp, vp, vp, vp]),
+        "orc_search_last_path": (i32, [vp, vp]),
+        "orc_search_set_rng": (None, [vp, u64]),
+        "orc_choose_child": (i32, [vp, i32, C.c_float, C.c_float]),
+        "orc_selfplay_game": (C.POINTER(Trace), [C.POINTER(SelfplayCfg), vp, vp]),
+        "orc_trace_free": (None, [C.POINTER(Trace)]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def uci(m):
+    buf = C.create_string_buffer(8)
+    lib().orc_move_uci(int(m), buf)
+    return buf.value.decode()
+
+
+def from_uci(s):
+    return int(lib().orc_move_from_uci(s.encode()))
+
+
+TERMINATION = {1: "Checkmate", 2: "Stalemate", 3: "InsufficientMaterial", 4: "SeventyfiveMoves",
+               5: "FivefoldRepetition", 6: "FiftyMoves", 7: "ThreefoldRepetition"}
+
+
+class State:
+    """python-chess Board look-alike over the oracle (only what the tests need)."""
+
+    def __init__(self, fen=None):
+        self.L = lib()
+        self.h = self.L.orc_state_new()
+        if fen is not None:
+            assert self.L.orc_state_set_fen(self.h, fen.encode()) == 0, fen
+
+    def __del__(self):
+        try:
+            self.L.orc_state_free(self.h)
+        except Exception:
+            pass
+
+    def copy(self):
+        o = State()
+        self.L.orc_state_copy(o.h, self.h)
+        return o
+
+    @property
+    def turn(self):
+        return self.L.orc_turn(self.h)
+
+    @property
+    def ply(self):
+        return self.L.orc_ply(self.h)
+
+    def fen(self):
+        buf = C.create_string_buffer(128)
+        self.L.orc_fen(self.h, buf, 128)
+        return buf.value.decode()
+
+    def piece_at(self, sq):
+        return self.L.orc_piece_at(self.h, sq)
+
+    def push(self, m):
+        if isinstance(m, str):
+            m = from_uci(m)
+        self.L.orc_push(self.h, m)
+
+    def pop(self):
+        return self.L.orc_pop(self.h)
+
+    def legal_moves(self):
+        buf = (C.c_uint16 * MAX_MOVES)()
+        n = self.L.orc_legal_moves(self.h, buf)
+        return [int(buf[i]) for i in range(n)]
+
+    def legal_uci(self):
+        return [uci(m) for m in self.legal_moves()]
+
+    def is_check(self):
+        return bool(self.L.orc_is_check(self.h))
+
+    def perft(self, depth):
+        return int(self.L.orc_perft(self.h, depth))
+
+    def is_repetition(self, count):
+        return bool(self.L.orc_is_repetition(self.h, count))
+
+    def outcome(self):
+        t, w = C.c_int(0), C.c_int(0)
+        if not self.L.orc_outcome(self.h, C.byref(t), C.byref(w)):
+            return None
+        return {"termination": TERMINATION[t.value], "winner": {1: "White", 0: "Black", -1: None}[w.value]}
+
+    def encode(self):
+        boards = np.zeros((8, 8, 112), np.int8)
+        meta = np.zeros(7, np.int32)
+        self.L.orc_encode(self.h, _ptr(boards), _ptr(meta))
+        return boards, meta
+
+    def pos_hash(self):
+        return int(self.L.orc_pos_hash(self.h))
+
+
+def move_index(m, turn):
+    if isinstance(m, str):
+        m = from_uci(m)
+    return int(lib().orc_move_index(m, turn))
+
+
+class Net:
+    def __init__(self, n_blocks, channels=256, seed=0, emulate_bf16=False):
+        self.L = lib()
+        self.n_blocks, self.channels = n_blocks, channels
+        self.h = self.L.orc_net_create(n_blocks, channels, seed, int(emulate_bf16))
+
+    def __del__(self):
+        try:
+            self.L.orc_net_free(self.h)
+        except Exception:
+            pass
+
+    def num_tensors(self):
+        return self.L.orc_net_num_tensors(self.n_blocks)
+
+    def tensor_shape(self, t):
+        shape = (C.c_int * 4)()
+        nd = C.c_int(0)
+        self.L.orc_net_tensor_shape(self.n_blocks, self.channels, t, shape, C.byref(nd))
+        return tuple(shape[i] for i in range(nd.value))
+
+    def get_tensor(self, t):
+        a = np.zeros(self.tensor_shape(t), np.float32)
+        assert self.L.orc_net_get_tensor(self.h, t, _ptr(a), a.size) == 0
+        return a
+
+    def set_tensor(self, t, a):
+        a = np.ascontiguousarray(a, np.float32)
+        assert self.L.orc_net_set_tensor(self.h, t, _ptr(a), a.size) == 0
+
+    def forward(self, boards, meta, latent=False):
+        boards = np.ascontiguousarray(boards, np.int8)
+        meta = np.ascontiguousarray(meta, np.int32)
+        logp = np.zeros(4672, np.float32)
+        v = np.zeros(1, np.float32)
+        lat = np.zeros((64, self.channels), np.float32) if latent else None
+        self.L.orc_net_forward(self.h, _ptr(boards), _ptr(meta), _ptr(logp), _ptr(v), _ptr(lat) if latent else None)
+        return (logp, float(v[0]), lat) if latent else (logp, float(v[0]))
+
+
+def eval_fn(name):
+    """address of a built-in evaluator"""
+    return C.cast(getattr(lib(), name), C.c_void_p)
+
+
+class Search:
+    def __init__(self, state, depth=0):
+        self.L = lib()
+        self.h = self.L.orc_search_new(state.h, depth)
+
+    def __del__(self):
+        try:
+            self.L.orc_search_free(self.h)
+        except Exception:
+            pass
+
+    def sim(self, evaluator="orc_eval_synth", user=None, cpuct=2.5, epsilon=0.15, with_noise=False, noise=None,
+            faithful=False):
+        ev = evaluator if not isinstance(evaluator, str) else eval_fn(evaluator)
+        nz = None
+        if noise is not None:
+            noise = np.ascontiguousarray(noise, np.float64)
+            nz = _ptr(noise)
+        self.L.orc_search_sim(self.h, ev, user, cpuct, epsilon, int(with_noise), nz, int(faithful))
+
+    def dump(self):
+        n = self.L.orc_search_num_nodes(self.h)
+        out = dict(parent=np.zeros(n, np.int32), move=np.zeros(n, np.uint16), n=np.zeros(n, np.int32),
+                   q=np.zeros(n, np.float32), uct=np.zeros(n, np.float32), first_child=np.zeros(n, np.int32),
+                   n_child=np.zeros(n, np.int32))
+        self.L.orc_search_dump(self.h, *[_ptr(out[k]) for k in ("parent", "move", "n", "q", "uct", "first_child",
+                                                                  "n_child")])
+        return out
+
+    def last_path(self):
+        p = np.zeros(MAX_PLY, np.int32)
+        n = self.L.orc_search_last_path(self.h, _ptr(p))
+        return p[:n].copy()
+
+    def num_evals(self):
+        return int(self.L.orc_search_num_evals(self.h))
+
+
+def selfplay_game(evaluator="orc_eval_synth", user=None, rollout_num=20, num_steps=150, cpuct=2.5,
+                  temperature=0.0, temperature_switch=4, epsilon=0.15, with_noise=True, faithful=False, seed=0,
+                  game_id=0, outcome_gate=100):
+    L = lib()
+    cfg = SelfplayCfg(rollout_num, num_steps, cpuct, temperature, temperature_switch, epsilon, int(with_noise),
+                      int(faithful), seed, game_id, outcome_gate)
+    ev = evaluator if not isinstance(evaluator, str) else eval_fn(evaluator)
+    tp = L.orc_selfplay_game(C.byref(cfg), ev, user)
+    t = tp.contents
+    steps = []
+    for i in range(t.n_steps):
+        ch = [(uci(t.child_move[j]), int(t.child_n[j]), float(t.child_q[j]), float(t.child_uct[j]))
+              for j in range(t.child_off[i], t.child_off[i + 1])]
+        steps.append((uci(t.moves[i]), float(t.q_root[i]), ch))
+    outcome = None
+    if t.has_outcome:
+        outcome = {"termination": TERMINATION[t.termination], "winner": {1: "White", 0: "Black", -1: None}[t.winner]}
+    res = {"steps": steps, "outcome": outcome, "n_sims": int(t.n_sims), "n_evals": int(t.n_evals)}
+    L.orc_trace_free(tp)
+    return res

@@ -1,0 +1,91 @@
+/*
+ * sc_oracle.h -- CPU ORACLE for the MCTS + NN self-play hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This is a plain-C restatement of the reference algorithm
+ * (pierric/smart-chess-rust) used as the *checker* for the HIP engine.  Only tests/,
+ * __graft_entry__.smoke() and bench.py's `cpu_baseline` leg may load it.  The product
+ * (smart-chess-rust_amd/) never links, imports or calls anything in this directory.
+ *
+ * What is restated, and from where (paths relative to the reference repo):
+ *   - chess rules ........ python-chess 1.11.1 (un-vendored third-party dependency of the
+ *                          reference, pyproject.toml:10): legal move generation *and its order*,
+ *                          push, is_repetition, outcome(claim_draw=True); call sites
+ *                          src/chess.rs:356-412, 665-803.  Written here as a mailbox board with
+ *                          make-move + king-attack legality (deliberately a different method from
+ *                          the product's bitboard/pin-mask generator so the two cross-check).
+ *   - action index ....... src/queenmoves.rs:3-34, src/knightmoves.rs:7-31,
+ *                          src/underpromotions.rs:6-33, src/chess.rs:504-551
+ *   - plane encoder ...... src/chess.rs:593-663, 805-877
+ *   - PUCT search ........ src/mcts.rs:61-328
+ *   - predict contract ... src/backends/torch.rs:89-175, src/chess.rs:879-903
+ *   - self-play driver ... src/main.rs:155-238, src/trace.rs:5-42
+ *   - network forward .... py/module.py:14-154 (fp32)
+ *
+ * Pinning: rules by public perft known answers + the reference's own fixtures (notebook move
+ * orders, py/validation/sample.csv games, chess_fast.rs FEN); network by golden vectors produced
+ * by importing py/module.py in the build container (tools/gen_golden_nn.py).  See DESIGN.md.
+ */
+#ifndef SC_ORACLE_H
+#define SC_ORACLE_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORC_MAX_PLY 1024
+#define ORC_MAX_MOVES 256
+#define ORC_WHITE 1
+#define ORC_BLACK 0
+
+/* piece types as python-chess: 1 pawn .. 6 king */
+/* move: from | to<<6 | promo<<12 (promo = 0 or piece type 2..5) */
+typedef uint16_t orc_move;
+
+typedef struct {
+    int8_t board[64]; /* 0 empty, +pt white, -pt black */
+    uint8_t turn;     /* 1 white */
+    uint8_t castling; /* bit0 h1, bit1 a1, bit2 h8, bit3 a8 (rook squares that keep rights) */
+    int8_t ep;        /* python-chess ep_square: set after ANY double push, else -1 */
+    int32_t halfmove;
+    int32_t fullmove;
+} orc_pos;
+
+typedef struct {
+    orc_pos cur;
+    int n;                         /* moves played */
+    orc_pos stack[ORC_MAX_PLY];    /* stack[i] = position before move i */
+    orc_move moves[ORC_MAX_PLY];
+} orc_state;
+
+/* ---- rules ---- */
+orc_state* orc_state_new(void);
+void orc_state_free(orc_state*);
+void orc_state_reset(orc_state*);
+int orc_state_set_fen(orc_state*, const char* fen); /* 0 ok */
+void orc_state_copy(orc_state* dst, const orc_state* src);
+int orc_fen(const orc_state*, char* buf, int cap);   /* python-chess Board.fen() (legal ep only) */
+int orc_turn(const orc_state*);
+int orc_ply(const orc_state*);
+int orc_piece_at(const orc_state*, int sq);          /* signed piece code */
+void orc_push(orc_state*, orc_move);
+orc_move orc_pop(orc_state*);
+int orc_legal_moves(const orc_state*, orc_move* out); /* python-chess order */
+int orc_is_check(const orc_state*);
+uint64_t orc_perft(orc_state*, int depth);
+int orc_is_repetition(const orc_state*, int count);
+/* outcome(claim_draw=True): returns 0 = None, else 1; termination numbering as src/chess.rs:88-99;
+ * winner: 1 white, 0 black, -1 none */
+int orc_outcome(orc_state*, int* termination, int* winner);
+int orc_move_uci(orc_move, char* buf);               /* returns strlen */
+orc_move orc_move_from_uci(const char*);
+
+/* ---- encoders ---- */
+int orc_move_index(orc_move m, int turn);            /* Move::encode after rotate-if-black */
+/* _encode(): boards int8[8][8][112], meta int32[7]; history limited to `n` plies back to root */
+void orc_encode(const orc_state*, int8_t* boards, int32_t* meta);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
