@@ -1,0 +1,176 @@
+/*
+ * sc_engine.h -- C ABI of libsc_engine.so, the MI355X-native drop-in for the MCTS + NN rollout
+ * hot path of pierric/smart-chess-rust.
+ *
+ * Plain pointers and sizes only (no torch / C++ types).  Every entry point returns 0 on success
+ * and a negative code on failure; sc_last_error() gives the thread-local message.  Nothing aborts
+ * across the ABI (the reference unwrap()s/panics instead: src/backends/torch.rs:27-31,100,111).
+ * A handle is bound to one GPU and must be driven by one host thread at a time; distinct handles
+ * (one per GPU) are independent -- this is how games shard over the 8 GPUs of a node.
+ *
+ * Two levels, as laid out in SURVEY.md section 8(b):
+ *
+ *  L-predict  -- the reference's `trait Game<S>::predict` contract (src/game.rs:3-15) as
+ *                implemented by src/backends/torch.rs:89-146 / src/backends/onnx.rs:14-56,
+ *                batched.  The reference-side binding is a `impl Game<BoardState> for ChessHip`
+ *                (INTEGRATION.md).
+ *  L-search   -- the whole per-game loop of src/main.rs:155-238 (mcts::mcts src/mcts.rs:237-289,
+ *                mcts::step :292-328, Trace src/trace.rs:5-42) for many concurrent games on one GPU.
+ *
+ * Layout conventions (identical to the reference's post-_encode tensors):
+ *   boards : int8  [n][8][8][112]  (rank, file, plane)      src/chess.rs:828-842, :845-877
+ *   meta   : int32 [n][7]                                    src/chess.rs:652-662
+ *   moves  : uint16 = from | to<<6 | promo<<12, squares a1=0..h8=63, promo in python-chess piece
+ *            types (0 none, 2 N, 3 B, 4 R, 5 Q); castling is the king's two-square move (e1g1)
+ *   action index: rank*584 + file*73 + type after rotating Black's moves (src/chess.rs:504-551)
+ */
+#ifndef SC_ENGINE_H
+#define SC_ENGINE_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SC_MAX_MOVES 224      /* row stride of per-position move tables (218 is the chess maximum) */
+#define SC_POLICY_SIZE 4672   /* 8*8*73 */
+#define SC_BOARD_BYTES 7168   /* 8*8*112 */
+
+typedef struct sc_engine sc_engine;
+typedef struct sc_selfplay sc_selfplay;
+
+const char* sc_last_error(void);
+int sc_device_count(void);
+
+/* ------------------------------------------------------------------ network (L-predict) */
+typedef struct {
+    int32_t n_res_blocks;  /* py/module.py:110 (reference default 19) */
+    int32_t channels;      /* trunk width: 256 in the reference (py/module.py:120-133); 128 = BASELINE cfg2 variant */
+    uint64_t seed;         /* used when weights_path == NULL: build-owned deterministic init (tools/scw.py) */
+} sc_net_config;
+
+/* Replaces backend construction in src/main.rs:83-128 (ChessTS / ChessEP / ChessOnnx).
+ * weights_path: SCW1 blob written by tools/scw.py from a reference state_dict, or NULL. */
+int sc_engine_create(const sc_net_config* cfg, const char* weights_path, int device_id, sc_engine** out);
+void sc_engine_destroy(sc_engine*);
+int sc_engine_max_batch(const sc_engine*);
+
+/* ChessModule.forward on a batch (src/backends/torch.rs:115-125, py/module.py:135-154):
+ * host buffers in, logp [n][4672] fp32 (log-softmax, channel-major flatten) and value [n] out
+ * (value from White's point of view).  logp may be NULL. */
+int sc_forward_batch(sc_engine*, int n, const int8_t* boards, const int32_t* meta, float* logp, float* value);
+
+/* The post-_encode tail of Game::predict (src/backends/torch.rs:108-146): forward, gather the
+ * legal action logits, exp, renormalise by (sum + 1e-5) (src/chess.rs:891-901).
+ * legal_idx / priors are CSR: position i owns [legal_off[i], legal_off[i+1]). */
+int sc_predict_batch(sc_engine*, int n, const int8_t* boards, const int32_t* meta, const uint16_t* legal_idx,
+                     const uint32_t* legal_off, float* priors, float* value);
+
+/* Device-resident variant of sc_predict_batch used by the benchmark and by L-search: all
+ * pointers are device pointers, move tables have row stride SC_MAX_MOVES, launch is asynchronous
+ * on the engine's stream. */
+int sc_predict_batch_device(sc_engine*, int n, const int8_t* d_boards, const int32_t* d_meta,
+                            const uint16_t* d_legal_idx, const int32_t* d_n_legal, float* d_priors, float* d_value,
+                            float* d_logp_or_null);
+int sc_engine_synchronize(sc_engine*);
+/* test aid: fp32 residual stream [n][64][channels] after `stage` (0 = conv_block, b = res block b, 1000 = trunk output) */
+int sc_forward_debug(sc_engine*, int n, const int8_t* boards, const int32_t* meta, int stage, float* out);
+
+/* Rules + encoder on the GPU: replaces python-chess (src/chess.rs:665-803) and _encode
+ * (src/chess.rs:845-877) for positions given as move lists from the start position.
+ * For position i (moves[move_off[i]..move_off[i+1])):
+ *   boards[i], meta[i]                      the NN input
+ *   legal_moves[i][..], legal_idx[i][..]    legal moves in python-chess generation order and their
+ *                                           action indices (row stride SC_MAX_MOVES), n_legal[i]
+ *   outcome[i][0] = termination (src/chess.rs:88-99 numbering, 0 = none; outcome(claim_draw=True)),
+ *   outcome[i][1] = winner (1 white, 0 black, -1 none), outcome[i][2] = is_check, outcome[i][3] = 0 ok / <0 illegal move at that index-1
+ * Any output pointer may be NULL. */
+int sc_encode_positions(sc_engine* engine_or_null, int device_id, int n, const uint16_t* moves, const uint32_t* move_off,
+                        int8_t* boards, int32_t* meta, uint16_t* legal_moves, uint16_t* legal_idx, int32_t* n_legal,
+                        int32_t* outcome);
+
+/* ------------------------------------------------------------------ self-play (L-search) */
+enum { SC_EVAL_NET = 0, SC_EVAL_SYNTH = 1 }; /* SYNTH: integer-hash evaluator for exact search-parity tests */
+
+typedef struct {
+    int32_t n_slots;            /* concurrent games on this GPU (BASELINE cfg2: 256) */
+    int32_t n_games;            /* total games to play on this handle (slots are recycled) */
+    int32_t rollout_num;        /* --rollout-num      src/main.rs:32-33,175-180 */
+    int32_t num_steps;          /* -n/--num-steps     src/main.rs:35-36 */
+    float cpuct;                /* --cpuct            src/main.rs:50-51 */
+    float temperature;          /* --temperature      src/main.rs:47-48 */
+    int32_t temperature_switch; /* --temperature-switch src/main.rs:53-54 */
+    float epsilon;              /* --epsilon          src/main.rs:56-57 */
+    int32_t with_noise;         /* 1 in selfplay (src/main.rs:195), 0 for NNPlayer::bestmove (src/play.rs:250) */
+    int32_t outcome_gate;       /* outcome() is consulted only when ply index > gate (src/main.rs:223: 100) */
+    int32_t evaluator;          /* SC_EVAL_NET / SC_EVAL_SYNTH */
+    int32_t external_noise;     /* tests: root noise is taken from sc_selfplay_set_noise instead of the device RNG */
+    uint64_t seed;
+    uint64_t first_game_id;     /* global id of this handle's first game (sharding across GPUs/ranks) */
+} sc_selfplay_config;
+
+int sc_selfplay_create(sc_engine* engine_or_null, int device_id, const sc_selfplay_config* cfg, sc_selfplay** out);
+void sc_selfplay_destroy(sc_selfplay*);
+
+/* Enqueue `n` simulation steps (each = one iteration of src/mcts.rs:261-288 for every active
+ * game, including the per-ply move choice of mcts::step when a game's rollout count is reached). */
+int sc_selfplay_enqueue_sims(sc_selfplay*, int n);
+int sc_selfplay_synchronize(sc_selfplay*);
+/* Run until every game has finished (or max_sim_steps > 0 is reached). */
+int sc_selfplay_run(sc_selfplay*, int64_t max_sim_steps);
+
+typedef struct {
+    int64_t sims_done;       /* simulations completed, all games */
+    int64_t nn_evals;        /* leaf evaluations that needed the network */
+    int32_t games_finished;
+    int32_t games_active;
+    int32_t error_flags;     /* non-finite PUCT value etc. (reference panics: src/mcts.rs:202-214) */
+    int32_t plies_done;      /* total plies played over all games */
+} sc_selfplay_stats;
+int sc_selfplay_get_stats(sc_selfplay*, sc_selfplay_stats* out);
+/* HIP-event timing on the stream the kernels are launched on.  enable_timing(stride>0): every
+ * stride-th launch of the dominant kernel (the network tower) is bracketed by an event pair.
+ * timing(): ms_total = first enqueue -> last enqueue span; ms_nn = sum over the nn_launches sampled
+ * tower launches (at most the last 4096). */
+int sc_selfplay_enable_timing(sc_selfplay*, int stride);
+int sc_selfplay_timing(sc_selfplay*, int reset, float* ms_total, float* ms_nn, int64_t* nn_launches);
+
+/* Trace of a finished game = the reference's Trace<M,O> (src/trace.rs:5-9) in SoA form.
+ * Call with NULL arrays to query sizes first.  child_off has n_steps+1 entries. */
+typedef struct {
+    int32_t n_steps;
+    int32_t n_children_total;
+    int32_t has_outcome;   /* 0: outcome null (src/trace.rs:7), 1: set */
+    int32_t termination;   /* src/chess.rs:88-99 */
+    int32_t winner;        /* 1 white, 0 black, -1 none */
+    uint64_t game_id;
+} sc_trace_info;
+int sc_selfplay_get_trace(sc_selfplay*, int game /*0..n_games-1*/, sc_trace_info* info, uint16_t* step_move,
+                          float* step_q, int32_t* child_off, uint16_t* child_move, int32_t* child_n, float* child_q,
+                          float* child_uct);
+/* Writes the reference's trace JSON (src/trace.rs:23-32; serde_json pretty, keys "outcome","steps"). */
+int sc_selfplay_write_trace_json(sc_selfplay*, int game, const char* path);
+
+/* tests / NNPlayer::bestmove (src/play.rs:241-288) support: current search tree of a slot in
+ * allocation order (root = 0; children of a node contiguous).  Arrays may be NULL; returns n_nodes. */
+int sc_selfplay_get_tree(sc_selfplay*, int slot, int cap, int32_t* n, float* q, float* uct, float* prior, uint16_t* move,
+                         int32_t* first_child, int32_t* n_child);
+int sc_selfplay_get_slot(sc_selfplay*, int slot, int32_t* ply, int32_t* sim, int32_t* status, uint64_t* game_id,
+                         int32_t* last_path /*cap 1024*/, int32_t* last_path_len);
+/* replace the root noise used by the NEXT simulation of `slot` (external_noise mode); noise[n] */
+int sc_selfplay_set_noise(sc_selfplay*, int slot, const float* noise, int n);
+int sc_selfplay_get_noise(sc_selfplay*, int slot, float* noise, int cap);
+/* start slot from a given move list instead of the initial position (sc_search / chess_play_new, src/lib.rs:161-232) */
+int sc_selfplay_set_position(sc_selfplay*, int slot, const uint16_t* moves, int n_moves);
+
+/* utility: trace-file JSON writer on caller-provided arrays (no GPU needed) */
+int sc_trace_write_json(const char* path, const sc_trace_info* info, const uint16_t* step_move, const float* step_q,
+                        const int32_t* child_off, const uint16_t* child_move, const int32_t* child_n,
+                        const float* child_q, const float* child_uct);
+/* utility: UCI text of a move (src/chess.rs:513-519); returns strlen */
+int sc_move_uci(uint16_t move, char* buf8);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

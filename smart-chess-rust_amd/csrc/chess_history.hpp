@@ -34,7 +34,8 @@ enum { T_NONE = 0, T_CHECKMATE = 1, T_STALEMATE = 2, T_INSUFFICIENT = 3, T_SEVEN
 template <class Chain>
 SC_HD int outcome_claim_draw(const Chain& ch, int idx, int* winner) {
     const Position& p = ch.pos(idx);
-    MoveList l;
+    move_t buf1[MAX_MOVES], buf2[MAX_MOVES];
+    MoveList l{buf1, 0};
     bool in_check = gen_legal(p, l);
     *winner = -1;
     if (in_check && l.n == 0) {
@@ -51,7 +52,7 @@ SC_HD int outcome_claim_draw(const Chain& ch, int idx, int* winner) {
             if (is_zeroing(p, l.m[i])) continue;
             Position q = p;
             make_move(q, l.m[i]);
-            MoveList l2;
+            MoveList l2{buf2, 0};
             gen_legal(q, l2);
             if (q.halfmove >= 100 && l2.n > 0) return T_FIFTY;
         }

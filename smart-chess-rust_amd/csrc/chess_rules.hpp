@@ -314,8 +314,9 @@ SC_HD bb_t slider_blockers(const Position& p, int king) {
     return blockers & p.occ[us];
 }
 
+// caller-provided storage (LDS on the device, a local array on the host), capacity MAX_MOVES
 struct MoveList {
-    move_t m[MAX_MOVES];
+    move_t* m;
     int n;
 };
 

@@ -1,0 +1,743 @@
+// engine.hip -- host side of libsc_engine.so: the C ABI of include/sc_engine.h over the HIP kernels.
+//
+// Replaces, behind the reference's own interfaces: backend construction + Game::predict
+// (src/main.rs:83-128, src/backends/torch.rs:89-146), the rules/encoder calls into python-chess
+// (src/chess.rs:665-877) and the per-game self-play loop (src/main.rs:155-238) -- the latter for
+// many concurrent games per GPU.  All compute runs on the GPU; there is no CPU fallback: every
+// entry point fails with an error code if HIP or the device is unavailable.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "../../include/sc_engine.h"
+#include "launchers.hpp"
+#include "trace_json.hpp"
+#include "weights.hpp"
+
+static thread_local std::string g_err;
+static int fail(const std::string& m, int code = -1) {
+    g_err = m;
+    return code;
+}
+#define HIPOK(expr)                                                                                   \
+    do {                                                                                              \
+        hipError_t e_ = (expr);                                                                       \
+        if (e_ != hipSuccess) return fail(std::string(#expr) + ": " + hipGetErrorString(e_), -2);     \
+    } while (0)
+
+template <class T>
+static hipError_t dalloc(T** p, size_t n) {
+    return hipMalloc(reinterpret_cast<void**>(p), std::max<size_t>(n, 1) * sizeof(T));
+}
+
+struct sc_engine {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    scnn::NetDev net{};
+    uint16_t* d_wb = nullptr;
+    float* d_wf = nullptr;
+    int ksplit = 32;
+    // scratch, grown on demand
+    int cap = 0;
+    int8_t* d_boards = nullptr;
+    int32_t* d_meta = nullptr;
+    uint16_t* d_lidx = nullptr;
+    int32_t* d_nlegal = nullptr;
+    float* d_prior = nullptr;
+    float* d_value = nullptr;
+    float* d_logp = nullptr;
+    scnn::bf16_t* d_hval = nullptr;
+    float* d_vpart = nullptr;
+    float* d_dbg = nullptr;
+};
+
+static void engine_free_scratch(sc_engine* e) {
+    (void)hipFree(e->d_boards); hipFree(e->d_meta); hipFree(e->d_lidx); hipFree(e->d_nlegal); hipFree(e->d_prior);
+    (void)hipFree(e->d_value); hipFree(e->d_logp); hipFree(e->d_hval); hipFree(e->d_vpart); hipFree(e->d_dbg);
+    e->d_boards = nullptr; e->d_meta = nullptr; e->d_lidx = nullptr; e->d_nlegal = nullptr; e->d_prior = nullptr;
+    e->d_value = nullptr; e->d_logp = nullptr; e->d_hval = nullptr; e->d_vpart = nullptr; e->d_dbg = nullptr;
+    e->cap = 0;
+}
+static int engine_reserve(sc_engine* e, int n) {
+    if (n <= e->cap) return 0;
+    HIPOK(hipStreamSynchronize(e->stream));
+    engine_free_scratch(e);
+    int cap = std::max(n, 64);
+    HIPOK(dalloc(&e->d_boards, (size_t)cap * 7168));
+    HIPOK(dalloc(&e->d_meta, (size_t)cap * 8));
+    HIPOK(dalloc(&e->d_lidx, (size_t)cap * 224));
+    HIPOK(dalloc(&e->d_nlegal, (size_t)cap));
+    HIPOK(dalloc(&e->d_prior, (size_t)cap * 224));
+    HIPOK(dalloc(&e->d_value, (size_t)cap));
+    HIPOK(dalloc(&e->d_logp, (size_t)cap * 4672));
+    HIPOK(dalloc(&e->d_hval, (size_t)cap * 64 * 256));
+    HIPOK(dalloc(&e->d_vpart, (size_t)e->ksplit * cap * 128));
+    HIPOK(dalloc(&e->d_dbg, (size_t)cap * 64 * 256));
+    e->cap = cap;
+    return 0;
+}
+
+// enqueue the three network kernels for n positions (device pointers)
+static void enqueue_forward(sc_engine* e, int n, const int8_t* boards, const int32_t* meta, int meta_stride,
+                            const uint16_t* lidx, const int32_t* nlegal, float* prior, float* value, float* logp, float* dbg,
+                            int dbg_stage, hipStream_t s) {
+    scnn::TowerArgs t{};
+    t.net = e->net;
+    t.n_pos = n;
+    t.boards = boards;
+    t.meta = meta;
+    t.meta_stride = meta_stride;
+    t.legal_idx = lidx;
+    t.n_legal = nlegal;
+    t.prior = (lidx && nlegal) ? prior : nullptr;
+    t.logp = logp;
+    t.hval = e->d_hval;
+    t.dbg = dbg;
+    t.dbg_stage = dbg ? dbg_stage : -1;
+    scl::tower(t, s);
+    scnn::Fc1Args f{};
+    f.net = e->net;
+    f.n_pos = n;
+    f.ksplit = e->ksplit;
+    f.hval = e->d_hval;
+    f.vpart = e->d_vpart;
+    scl::value_fc1(f, s);
+    scnn::VfinArgs v{};
+    v.net = e->net;
+    v.n_pos = n;
+    v.ksplit = e->ksplit;
+    v.vpart = e->d_vpart;
+    v.meta = meta;
+    v.meta_stride = meta_stride;
+    v.value = value;
+    scl::value_finish(v, s);
+}
+
+extern "C" {
+
+const char* sc_last_error(void) { return g_err.c_str(); }
+
+int sc_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int sc_engine_create(const sc_net_config* cfg, const char* weights_path, int device_id, sc_engine** out) {
+    if (!cfg || !out) return fail("null argument");
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail("no HIP device available: libsc_engine has no CPU fallback", -3);
+    if (device_id < 0 || device_id >= ndev) return fail("device_id out of range");
+    HIPOK(hipSetDevice(device_id));
+    scw::HostWeights hw;
+    if (weights_path) {
+        std::string err = scw::load_scw(weights_path, hw);
+        if (!err.empty()) return fail(err);
+    } else {
+        if (cfg->channels != 128 && cfg->channels != 256) return fail("channels must be 128 or 256");
+        if (cfg->n_res_blocks < 0 || cfg->n_res_blocks > 80) return fail("n_res_blocks out of range");
+        hw = scw::init_prng(cfg->n_res_blocks, cfg->channels, cfg->seed);
+    }
+    scw::Packed pk = scw::pack(hw);
+    sc_engine* e = new sc_engine();
+    e->device = device_id;
+    const char* ierr = scl::nn_init();
+    if (ierr) {
+        delete e;
+        return fail(std::string("kernel attribute setup failed: ") + ierr);
+    }
+    HIPOK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    HIPOK(dalloc(&e->d_wb, pk.wb.size()));
+    HIPOK(dalloc(&e->d_wf, pk.wf.size()));
+    HIPOK(hipMemcpy(e->d_wb, pk.wb.data(), pk.wb.size() * 2, hipMemcpyHostToDevice));
+    HIPOK(hipMemcpy(e->d_wf, pk.wf.data(), pk.wf.size() * 4, hipMemcpyHostToDevice));
+    static_cast<scnn::NetLayout&>(e->net) = pk.lay;
+    e->net.wb = e->d_wb;
+    e->net.wf = e->d_wf;
+    *out = e;
+    return 0;
+}
+
+void sc_engine_destroy(sc_engine* e) {
+    if (!e) return;
+    hipSetDevice(e->device);
+    hipStreamSynchronize(e->stream);
+    engine_free_scratch(e);
+    (void)hipFree(e->d_wb);
+    (void)hipFree(e->d_wf);
+    hipStreamDestroy(e->stream);
+    delete e;
+}
+
+int sc_engine_max_batch(const sc_engine*) { return 65536; }
+int sc_engine_synchronize(sc_engine* e) {
+    if (!e) return fail("null engine");
+    HIPOK(hipSetDevice(e->device));
+    HIPOK(hipStreamSynchronize(e->stream));
+    return 0;
+}
+
+static int forward_host(sc_engine* e, int n, const int8_t* boards, const int32_t* meta, const uint16_t* lidx_rows,
+                        const int32_t* nlegal, float* prior_rows, float* value, float* logp, float* dbg, int dbg_stage) {
+    if (!e || !boards || !meta || n < 0) return fail("bad argument");
+    if (n == 0) return 0;
+    HIPOK(hipSetDevice(e->device));
+    int rc = engine_reserve(e, n);
+    if (rc) return rc;
+    hipStream_t s = e->stream;
+    HIPOK(hipMemcpyAsync(e->d_boards, boards, (size_t)n * 7168, hipMemcpyHostToDevice, s));
+    {
+        std::vector<int32_t> m8((size_t)n * 8, 0);
+        for (int i = 0; i < n; i++)
+            for (int k = 0; k < 7; k++) m8[(size_t)i * 8 + k] = meta[(size_t)i * 7 + k];
+        HIPOK(hipMemcpy(e->d_meta, m8.data(), m8.size() * 4, hipMemcpyHostToDevice));
+    }
+    if (lidx_rows) {
+        HIPOK(hipMemcpyAsync(e->d_lidx, lidx_rows, (size_t)n * 224 * 2, hipMemcpyHostToDevice, s));
+        HIPOK(hipMemcpyAsync(e->d_nlegal, nlegal, (size_t)n * 4, hipMemcpyHostToDevice, s));
+    }
+    enqueue_forward(e, n, e->d_boards, e->d_meta, 8, lidx_rows ? e->d_lidx : nullptr, lidx_rows ? e->d_nlegal : nullptr,
+                    e->d_prior, e->d_value, logp ? e->d_logp : nullptr, dbg ? e->d_dbg : nullptr, dbg_stage, s);
+    HIPOK(hipGetLastError());
+    if (value) HIPOK(hipMemcpyAsync(value, e->d_value, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    if (logp) HIPOK(hipMemcpyAsync(logp, e->d_logp, (size_t)n * 4672 * 4, hipMemcpyDeviceToHost, s));
+    if (prior_rows) HIPOK(hipMemcpyAsync(prior_rows, e->d_prior, (size_t)n * 224 * 4, hipMemcpyDeviceToHost, s));
+    if (dbg) HIPOK(hipMemcpyAsync(dbg, e->d_dbg, (size_t)n * 64 * e->net.C * 4, hipMemcpyDeviceToHost, s));
+    HIPOK(hipStreamSynchronize(s));
+    return 0;
+}
+
+int sc_forward_batch(sc_engine* e, int n, const int8_t* boards, const int32_t* meta, float* logp, float* value) {
+    return forward_host(e, n, boards, meta, nullptr, nullptr, nullptr, value, logp, nullptr, -1);
+}
+
+/* debugging aid for tests: residual stream after `stage` (0 stem, b block b, 1000 latent): out[n][64][C] */
+int sc_forward_debug(sc_engine* e, int n, const int8_t* boards, const int32_t* meta, int stage, float* out) {
+    return forward_host(e, n, boards, meta, nullptr, nullptr, nullptr, nullptr, nullptr, out, stage);
+}
+
+int sc_predict_batch(sc_engine* e, int n, const int8_t* boards, const int32_t* meta, const uint16_t* legal_idx,
+                     const uint32_t* legal_off, float* priors, float* value) {
+    if (!legal_idx || !legal_off || !priors) return fail("bad argument");
+    std::vector<uint16_t> rows((size_t)n * 224, 0);
+    std::vector<int32_t> nl((size_t)n);
+    for (int i = 0; i < n; i++) {
+        uint32_t a = legal_off[i], b = legal_off[i + 1];
+        if (b < a || b - a > 218) return fail("legal_off: more than 218 moves for one position");
+        nl[(size_t)i] = (int32_t)(b - a);
+        for (uint32_t k = a; k < b; k++) {
+            if (legal_idx[k] >= 4672) return fail("legal_idx out of range");
+            rows[(size_t)i * 224 + (k - a)] = legal_idx[k];
+        }
+    }
+    std::vector<float> pr((size_t)n * 224);
+    int rc = forward_host(e, n, boards, meta, rows.data(), nl.data(), pr.data(), value, nullptr, nullptr, -1);
+    if (rc) return rc;
+    for (int i = 0; i < n; i++)
+        for (int k = 0; k < nl[(size_t)i]; k++) priors[legal_off[i] + (uint32_t)k] = pr[(size_t)i * 224 + k];
+    return 0;
+}
+
+int sc_predict_batch_device(sc_engine* e, int n, const int8_t* d_boards, const int32_t* d_meta, const uint16_t* d_legal_idx,
+                            const int32_t* d_n_legal, float* d_priors, float* d_value, float* d_logp_or_null) {
+    if (!e || n < 0) return fail("bad argument");
+    HIPOK(hipSetDevice(e->device));
+    int rc = engine_reserve(e, n);
+    if (rc) return rc;
+    enqueue_forward(e, n, d_boards, d_meta, 7, d_legal_idx, d_n_legal, d_priors, d_value, d_logp_or_null, nullptr, -1, e->stream);
+    HIPOK(hipGetLastError());
+    return 0;
+}
+
+int sc_encode_positions(sc_engine* e, int device_id, int n, const uint16_t* moves, const uint32_t* move_off, int8_t* boards,
+                        int32_t* meta, uint16_t* legal_moves, uint16_t* legal_idx, int32_t* n_legal, int32_t* outcome) {
+    if (n < 0 || !move_off) return fail("bad argument");
+    if (n == 0) return 0;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail("no HIP device available: libsc_engine has no CPU fallback", -3);
+    int dev = e ? e->device : device_id;
+    HIPOK(hipSetDevice(dev));
+    uint32_t total = move_off[n];
+    uint32_t maxlen = 0;
+    for (int i = 0; i < n; i++) {
+        if (move_off[i + 1] < move_off[i]) return fail("move_off not monotonic");
+        maxlen = std::max(maxlen, move_off[i + 1] - move_off[i]);
+    }
+    if (maxlen > 4000) return fail("move list too long");
+    int hist_cap = (int)maxlen + 2;
+    uint16_t* d_moves = nullptr;
+    uint32_t* d_off = nullptr;
+    sc::Position* d_hist = nullptr;
+    int8_t* d_boards = nullptr;
+    int32_t *d_meta = nullptr, *d_nl = nullptr, *d_out = nullptr;
+    uint16_t *d_lm = nullptr, *d_li = nullptr;
+    HIPOK(dalloc(&d_moves, total));
+    HIPOK(dalloc(&d_off, (size_t)n + 1));
+    HIPOK(dalloc(&d_hist, (size_t)n * hist_cap));
+    HIPOK(dalloc(&d_boards, (size_t)n * 7168));
+    HIPOK(dalloc(&d_meta, (size_t)n * 7));
+    HIPOK(dalloc(&d_nl, (size_t)n));
+    HIPOK(dalloc(&d_out, (size_t)n * 4));
+    HIPOK(dalloc(&d_lm, (size_t)n * 224));
+    HIPOK(dalloc(&d_li, (size_t)n * 224));
+    if (total) HIPOK(hipMemcpy(d_moves, moves, (size_t)total * 2, hipMemcpyHostToDevice));
+    HIPOK(hipMemcpy(d_off, move_off, ((size_t)n + 1) * 4, hipMemcpyHostToDevice));
+    HIPOK(hipMemset(d_lm, 0, (size_t)n * 224 * 2));
+    HIPOK(hipMemset(d_li, 0, (size_t)n * 224 * 2));
+    scl::encode_positions(n, d_moves, d_off, d_hist, hist_cap, d_boards, d_meta, d_lm, d_li, d_nl, d_out, nullptr);
+    HIPOK(hipGetLastError());
+    HIPOK(hipDeviceSynchronize());
+    if (boards) HIPOK(hipMemcpy(boards, d_boards, (size_t)n * 7168, hipMemcpyDeviceToHost));
+    if (meta) HIPOK(hipMemcpy(meta, d_meta, (size_t)n * 7 * 4, hipMemcpyDeviceToHost));
+    if (legal_moves) HIPOK(hipMemcpy(legal_moves, d_lm, (size_t)n * 224 * 2, hipMemcpyDeviceToHost));
+    if (legal_idx) HIPOK(hipMemcpy(legal_idx, d_li, (size_t)n * 224 * 2, hipMemcpyDeviceToHost));
+    if (n_legal) HIPOK(hipMemcpy(n_legal, d_nl, (size_t)n * 4, hipMemcpyDeviceToHost));
+    if (outcome) HIPOK(hipMemcpy(outcome, d_out, (size_t)n * 16, hipMemcpyDeviceToHost));
+    (void)hipFree(d_moves); hipFree(d_off); hipFree(d_hist); hipFree(d_boards); hipFree(d_meta); hipFree(d_nl); hipFree(d_out);
+    (void)hipFree(d_lm); hipFree(d_li);
+    return 0;
+}
+
+}  // extern "C"
+
+// ============================================================================================
+// self-play
+// ============================================================================================
+struct sc_selfplay {
+    sc_engine* engine = nullptr;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    sc_selfplay_config cfg{};
+    sc::SpParams p{};
+    std::vector<void*> allocs;
+    int64_t sim_steps_enqueued = 0;
+    // timing
+    int timing_stride = 0;
+    std::vector<hipEvent_t> ev;  // pairs
+    int ev_next = 0;
+    int64_t ev_recorded = 0;
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+    bool have_span = false;
+    int64_t nn_launches = 0;
+};
+
+template <class T>
+static int sp_alloc(sc_selfplay* sp, T** ptr, size_t n, bool zero = true) {
+    HIPOK(dalloc(ptr, n));
+    sp->allocs.push_back(*ptr);
+    if (zero) HIPOK(hipMemset(*ptr, 0, std::max<size_t>(n, 1) * sizeof(T)));
+    return 0;
+}
+
+extern "C" {
+
+int sc_selfplay_create(sc_engine* e, int device_id, const sc_selfplay_config* cfg, sc_selfplay** out) {
+    if (!cfg || !out) return fail("null argument");
+    *out = nullptr;
+    if (cfg->evaluator == SC_EVAL_NET && !e) return fail("SC_EVAL_NET needs an engine");
+    if (cfg->n_slots <= 0 || cfg->n_games <= 0 || cfg->rollout_num < 1 || cfg->num_steps < 1 || cfg->num_steps > 4000)
+        return fail("bad self-play configuration");
+    if (cfg->rollout_num > 60000) return fail("rollout_num too large");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail("no HIP device available: libsc_engine has no CPU fallback", -3);
+    int dev = e ? e->device : device_id;
+    if (dev < 0 || dev >= ndev) return fail("device_id out of range");
+    HIPOK(hipSetDevice(dev));
+    sc_selfplay* sp = new sc_selfplay();
+    sp->engine = e;
+    sp->device = dev;
+    sp->cfg = *cfg;
+    if (e) {
+        sp->stream = e->stream;
+    } else {
+        HIPOK(hipStreamCreateWithFlags(&sp->stream, hipStreamNonBlocking));
+        sp->own_stream = true;
+    }
+    sc::SpParams& p = sp->p;
+    p.n_slots = cfg->n_slots;
+    p.rollout = cfg->rollout_num;
+    p.num_steps = cfg->num_steps;
+    p.temp_switch = cfg->temperature_switch;
+    p.with_noise = cfg->with_noise;
+    p.outcome_gate = cfg->outcome_gate;
+    p.evaluator = cfg->evaluator;
+    p.external_noise = cfg->external_noise;
+    p.cpuct = cfg->cpuct;
+    p.temperature = cfg->temperature;
+    p.epsilon = cfg->epsilon;
+    p.seed = cfg->seed;
+    p.first_game_id = cfg->first_game_id;
+    p.node_cap = 1 + cfg->rollout_num * 218;         // worst case: every expansion adds 218 children
+    p.max_depth = cfg->rollout_num + 2;
+    p.hist_cap = cfg->num_steps + 2 + 600;           // room for sc_selfplay_set_position prefixes
+    p.tpos_cap = cfg->rollout_num + 2;
+    p.trace_cap = cfg->n_games;
+    p.total_games = cfg->n_games;
+    const size_t G = (size_t)cfg->n_slots, NC = (size_t)p.node_cap;
+    int rc = 0;
+    rc |= sp_alloc(sp, &p.ctl, G);
+    rc |= sp_alloc(sp, &p.hist, G * p.hist_cap, false);
+    rc |= sp_alloc(sp, &p.tpos, G * p.tpos_cap, false);
+    rc |= sp_alloc(sp, &p.path, G * p.max_depth);
+    rc |= sp_alloc(sp, &p.N, G * NC, false);
+    rc |= sp_alloc(sp, &p.W, G * NC, false);
+    rc |= sp_alloc(sp, &p.P, G * NC, false);
+    rc |= sp_alloc(sp, &p.U, G * NC, false);
+    rc |= sp_alloc(sp, &p.MV, G * NC, false);
+    rc |= sp_alloc(sp, &p.NC, G * NC, false);
+    rc |= sp_alloc(sp, &p.FC, G * NC, false);
+    rc |= sp_alloc(sp, &p.PS, G * NC, false);
+    rc |= sp_alloc(sp, &p.boards, G * 7168);
+    rc |= sp_alloc(sp, &p.meta, G * 8);
+    rc |= sp_alloc(sp, &p.legal_mv, G * 224);
+    rc |= sp_alloc(sp, &p.legal_idx, G * 224);
+    rc |= sp_alloc(sp, &p.n_legal, G);
+    rc |= sp_alloc(sp, &p.prior, G * 224);
+    rc |= sp_alloc(sp, &p.value, G);
+    rc |= sp_alloc(sp, &p.noise, G * 224);
+    const size_t T = (size_t)p.trace_cap, S = (size_t)p.num_steps;
+    rc |= sp_alloc(sp, &p.thdr, T);
+    rc |= sp_alloc(sp, &p.t_move, T * S);
+    rc |= sp_alloc(sp, &p.t_q, T * S);
+    rc |= sp_alloc(sp, &p.t_nchild, T * S);
+    rc |= sp_alloc(sp, &p.t_cmove, T * S * 224, false);
+    rc |= sp_alloc(sp, &p.t_cn, T * S * 224, false);
+    rc |= sp_alloc(sp, &p.t_cq, T * S * 224, false);
+    rc |= sp_alloc(sp, &p.t_cu, T * S * 224, false);
+    rc |= sp_alloc(sp, &p.cnt, 1);
+    if (rc) {
+        std::string keep = g_err;
+        sc_selfplay_destroy(sp);
+        return fail("self-play allocation failed: " + keep, -2);
+    }
+    if (e) {
+        rc = engine_reserve(e, cfg->n_slots);
+        if (rc) {
+            sc_selfplay_destroy(sp);
+            return rc;
+        }
+    }
+    scl::init_slots(p, sp->stream);
+    HIPOK(hipGetLastError());
+    HIPOK(hipStreamSynchronize(sp->stream));
+    *out = sp;
+    return 0;
+}
+
+void sc_selfplay_destroy(sc_selfplay* sp) {
+    if (!sp) return;
+    hipSetDevice(sp->device);
+    if (sp->stream) hipStreamSynchronize(sp->stream);
+    for (void* a : sp->allocs) hipFree(a);
+    for (hipEvent_t ev : sp->ev) hipEventDestroy(ev);
+    if (sp->ev_begin) hipEventDestroy(sp->ev_begin);
+    if (sp->ev_end) hipEventDestroy(sp->ev_end);
+    if (sp->own_stream) hipStreamDestroy(sp->stream);
+    delete sp;
+}
+
+int sc_selfplay_enable_timing(sc_selfplay* sp, int stride) {
+    if (!sp) return fail("null handle");
+    HIPOK(hipSetDevice(sp->device));
+    sp->timing_stride = stride;
+    if (stride > 0 && sp->ev.empty()) {
+        sp->ev.resize(2 * 4096);
+        for (auto& ev : sp->ev) HIPOK(hipEventCreate(&ev));
+        HIPOK(hipEventCreate(&sp->ev_begin));
+        HIPOK(hipEventCreate(&sp->ev_end));
+    }
+    return 0;
+}
+
+int sc_selfplay_enqueue_sims(sc_selfplay* sp, int n) {
+    if (!sp || n < 0) return fail("bad argument");
+    HIPOK(hipSetDevice(sp->device));
+    hipStream_t s = sp->stream;
+    const sc::SpParams& p = sp->p;
+    if (sp->timing_stride > 0 && !sp->have_span) {
+        HIPOK(hipEventRecord(sp->ev_begin, s));
+        sp->have_span = true;
+    }
+    for (int i = 0; i < n; i++) {
+        scl::select(p, s);
+        if (p.evaluator == SC_EVAL_SYNTH) {
+            scl::synth_eval(p, s);
+        } else {
+            sc_engine* e = sp->engine;
+            bool timed = sp->timing_stride > 0 && (sp->nn_launches % sp->timing_stride) == 0;
+            int slot = 0;
+            if (timed) {
+                slot = sp->ev_next;
+                sp->ev_next = (sp->ev_next + 1) % 4096;
+                HIPOK(hipEventRecord(sp->ev[2 * slot], s));
+            }
+            // tower only inside the timed bracket: it is the dominant kernel priced by the roofline
+            scnn::TowerArgs t{};
+            t.net = e->net;
+            t.n_pos = p.n_slots;
+            t.boards = p.boards;
+            t.meta = p.meta;
+            t.meta_stride = 8;
+            t.legal_idx = p.legal_idx;
+            t.n_legal = p.n_legal;
+            t.prior = p.prior;
+            t.logp = nullptr;
+            t.hval = e->d_hval;
+            t.dbg = nullptr;
+            t.dbg_stage = -1;
+            scl::tower(t, s);
+            if (timed) {
+                HIPOK(hipEventRecord(sp->ev[2 * slot + 1], s));
+                sp->ev_recorded++;
+            }
+            scnn::Fc1Args f{};
+            f.net = e->net;
+            f.n_pos = p.n_slots;
+            f.ksplit = e->ksplit;
+            f.hval = e->d_hval;
+            f.vpart = e->d_vpart;
+            scl::value_fc1(f, s);
+            scnn::VfinArgs v{};
+            v.net = e->net;
+            v.n_pos = p.n_slots;
+            v.ksplit = e->ksplit;
+            v.vpart = e->d_vpart;
+            v.meta = p.meta;
+            v.meta_stride = 8;
+            v.value = p.value;
+            scl::value_finish(v, s);
+            sp->nn_launches++;
+        }
+        scl::expand_backup(p, s);
+    }
+    sp->sim_steps_enqueued += n;
+    if (sp->timing_stride > 0) HIPOK(hipEventRecord(sp->ev_end, s));
+    HIPOK(hipGetLastError());
+    return 0;
+}
+
+int sc_selfplay_synchronize(sc_selfplay* sp) {
+    if (!sp) return fail("null handle");
+    HIPOK(hipSetDevice(sp->device));
+    HIPOK(hipStreamSynchronize(sp->stream));
+    return 0;
+}
+
+int sc_selfplay_get_stats(sc_selfplay* sp, sc_selfplay_stats* out) {
+    if (!sp || !out) return fail("bad argument");
+    HIPOK(hipSetDevice(sp->device));
+    HIPOK(hipStreamSynchronize(sp->stream));
+    sc::Counters c;
+    HIPOK(hipMemcpy(&c, sp->p.cnt, sizeof c, hipMemcpyDeviceToHost));
+    std::vector<sc::GameCtl> ctl((size_t)sp->p.n_slots);
+    HIPOK(hipMemcpy(ctl.data(), sp->p.ctl, ctl.size() * sizeof(sc::GameCtl), hipMemcpyDeviceToHost));
+    int active = 0;
+    for (auto& g : ctl) active += g.status == sc::ST_ACTIVE;
+    out->sims_done = (int64_t)c.sims_done;
+    out->nn_evals = (int64_t)c.nn_evals;
+    out->games_finished = c.games_finished;
+    out->games_active = active;
+    out->error_flags = c.err;
+    out->plies_done = (int32_t)c.plies_done;
+    return 0;
+}
+
+int sc_selfplay_run(sc_selfplay* sp, int64_t max_sim_steps) {
+    if (!sp) return fail("null handle");
+    int64_t done = 0;
+    for (;;) {
+        int chunk = sp->p.rollout;
+        if (max_sim_steps > 0 && done + chunk > max_sim_steps) chunk = (int)(max_sim_steps - done);
+        if (chunk <= 0) break;
+        int rc = sc_selfplay_enqueue_sims(sp, chunk);
+        if (rc) return rc;
+        done += chunk;
+        sc_selfplay_stats st;
+        rc = sc_selfplay_get_stats(sp, &st);
+        if (rc) return rc;
+        if (st.games_active == 0) break;
+    }
+    return 0;
+}
+
+int sc_selfplay_timing(sc_selfplay* sp, int reset, float* ms_total, float* ms_nn, int64_t* nn_launches) {
+    if (!sp) return fail("null handle");
+    HIPOK(hipSetDevice(sp->device));
+    HIPOK(hipStreamSynchronize(sp->stream));
+    float tot = 0.f, nn = 0.f;
+    int64_t cnt = std::min<int64_t>(sp->ev_recorded, 4096);
+    if (sp->timing_stride > 0) {
+        if (sp->have_span) HIPOK(hipEventElapsedTime(&tot, sp->ev_begin, sp->ev_end));
+        for (int64_t k = 0; k < cnt; k++) {
+            int slot = (int)(((int64_t)sp->ev_next - 1 - k + 4096 * 2) % 4096);
+            float ms = 0.f;
+            HIPOK(hipEventElapsedTime(&ms, sp->ev[2 * slot], sp->ev[2 * slot + 1]));
+            nn += ms;
+        }
+    }
+    if (ms_total) *ms_total = tot;
+    if (ms_nn) *ms_nn = nn;          // sum over the `cnt` sampled tower launches
+    if (nn_launches) *nn_launches = cnt;
+    if (reset) {
+        sp->ev_recorded = 0;
+        sp->ev_next = 0;
+        sp->have_span = false;
+        sp->nn_launches = 0;
+    }
+    return 0;
+}
+
+int sc_selfplay_get_trace(sc_selfplay* sp, int game, sc_trace_info* info, uint16_t* step_move, float* step_q,
+                          int32_t* child_off, uint16_t* child_move, int32_t* child_n, float* child_q, float* child_uct) {
+    if (!sp || !info || game < 0 || game >= sp->p.trace_cap) return fail("bad argument");
+    HIPOK(hipSetDevice(sp->device));
+    HIPOK(hipStreamSynchronize(sp->stream));
+    const sc::SpParams& p = sp->p;
+    sc::TraceHdr h;
+    HIPOK(hipMemcpy(&h, p.thdr + game, sizeof h, hipMemcpyDeviceToHost));
+    if (!h.done) return fail("game not finished", 1);
+    const size_t S = (size_t)p.num_steps, base = (size_t)game * S;
+    int ns = h.n_steps;
+    std::vector<int32_t> nch((size_t)std::max(ns, 1));
+    if (ns) HIPOK(hipMemcpy(nch.data(), p.t_nchild + base, (size_t)ns * 4, hipMemcpyDeviceToHost));
+    int total = 0;
+    for (int i = 0; i < ns; i++) total += nch[(size_t)i];
+    info->n_steps = ns;
+    info->n_children_total = total;
+    info->has_outcome = h.has_outcome;
+    info->termination = h.termination;
+    info->winner = h.winner;
+    info->game_id = h.game_id;
+    if (step_move && ns) HIPOK(hipMemcpy(step_move, p.t_move + base, (size_t)ns * 2, hipMemcpyDeviceToHost));
+    if (step_q && ns) HIPOK(hipMemcpy(step_q, p.t_q + base, (size_t)ns * 4, hipMemcpyDeviceToHost));
+    if (child_off) {
+        int off = 0;
+        for (int i = 0; i < ns; i++) {
+            child_off[i] = off;
+            off += nch[(size_t)i];
+        }
+        child_off[ns] = off;
+    }
+    if (child_move || child_n || child_q || child_uct) {
+        int off = 0;
+        for (int i = 0; i < ns; i++) {
+            size_t src = (base + (size_t)i) * 224;
+            size_t n = (size_t)nch[(size_t)i];
+            if (child_move) HIPOK(hipMemcpy(child_move + off, p.t_cmove + src, n * 2, hipMemcpyDeviceToHost));
+            if (child_n) HIPOK(hipMemcpy(child_n + off, p.t_cn + src, n * 4, hipMemcpyDeviceToHost));
+            if (child_q) HIPOK(hipMemcpy(child_q + off, p.t_cq + src, n * 4, hipMemcpyDeviceToHost));
+            if (child_uct) HIPOK(hipMemcpy(child_uct + off, p.t_cu + src, n * 4, hipMemcpyDeviceToHost));
+            off += (int)n;
+        }
+    }
+    return 0;
+}
+
+int sc_trace_write_json(const char* path, const sc_trace_info* info, const uint16_t* step_move, const float* step_q,
+                        const int32_t* child_off, const uint16_t* child_move, const int32_t* child_n, const float* child_q,
+                        const float* child_uct) {
+    if (!path || !info) return fail("bad argument");
+    std::string js = sctrace::trace_to_json(info->n_steps, info->has_outcome, info->termination, info->winner, step_move, step_q,
+                                            child_off, child_move, child_n, child_q, child_uct);
+    FILE* f = fopen(path, "wb");
+    if (!f) return fail(std::string("cannot open ") + path);
+    size_t w = fwrite(js.data(), 1, js.size(), f);
+    fclose(f);
+    if (w != js.size()) return fail("short write");
+    return 0;
+}
+
+int sc_selfplay_write_trace_json(sc_selfplay* sp, int game, const char* path) {
+    sc_trace_info info;
+    int rc = sc_selfplay_get_trace(sp, game, &info, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+    if (rc) return rc;
+    std::vector<uint16_t> sm((size_t)info.n_steps + 1), cm((size_t)info.n_children_total + 1);
+    std::vector<float> sq((size_t)info.n_steps + 1), cq((size_t)info.n_children_total + 1), cu((size_t)info.n_children_total + 1);
+    std::vector<int32_t> co((size_t)info.n_steps + 2), cn((size_t)info.n_children_total + 1);
+    rc = sc_selfplay_get_trace(sp, game, &info, sm.data(), sq.data(), co.data(), cm.data(), cn.data(), cq.data(), cu.data());
+    if (rc) return rc;
+    return sc_trace_write_json(path, &info, sm.data(), sq.data(), co.data(), cm.data(), cn.data(), cq.data(), cu.data());
+}
+
+int sc_selfplay_get_tree(sc_selfplay* sp, int slot, int cap, int32_t* n, float* q, float* uct, float* prior, uint16_t* move,
+                         int32_t* first_child, int32_t* n_child) {
+    if (!sp || slot < 0 || slot >= sp->p.n_slots) return fail("bad argument");
+    HIPOK(hipSetDevice(sp->device));
+    HIPOK(hipStreamSynchronize(sp->stream));
+    const sc::SpParams& p = sp->p;
+    sc::GameCtl c;
+    HIPOK(hipMemcpy(&c, p.ctl + slot, sizeof c, hipMemcpyDeviceToHost));
+    int nn = std::min(c.n_nodes, cap);
+    size_t nb = (size_t)slot * p.node_cap;
+    if (nn > 0) {
+        if (n) HIPOK(hipMemcpy(n, p.N + nb, (size_t)nn * 4, hipMemcpyDeviceToHost));
+        if (q) HIPOK(hipMemcpy(q, p.W + nb, (size_t)nn * 4, hipMemcpyDeviceToHost));
+        if (uct) HIPOK(hipMemcpy(uct, p.U + nb, (size_t)nn * 4, hipMemcpyDeviceToHost));
+        if (prior) HIPOK(hipMemcpy(prior, p.P + nb, (size_t)nn * 4, hipMemcpyDeviceToHost));
+        if (move) HIPOK(hipMemcpy(move, p.MV + nb, (size_t)nn * 2, hipMemcpyDeviceToHost));
+        if (first_child) HIPOK(hipMemcpy(first_child, p.FC + nb, (size_t)nn * 4, hipMemcpyDeviceToHost));
+        if (n_child) {
+            std::vector<uint16_t> t((size_t)nn);
+            HIPOK(hipMemcpy(t.data(), p.NC + nb, (size_t)nn * 2, hipMemcpyDeviceToHost));
+            for (int i = 0; i < nn; i++) n_child[i] = t[(size_t)i];
+        }
+    }
+    return c.n_nodes;
+}
+
+int sc_selfplay_get_slot(sc_selfplay* sp, int slot, int32_t* ply, int32_t* sim, int32_t* status, uint64_t* game_id,
+                         int32_t* last_path, int32_t* last_path_len) {
+    if (!sp || slot < 0 || slot >= sp->p.n_slots) return fail("bad argument");
+    HIPOK(hipSetDevice(sp->device));
+    HIPOK(hipStreamSynchronize(sp->stream));
+    sc::GameCtl c;
+    HIPOK(hipMemcpy(&c, sp->p.ctl + slot, sizeof c, hipMemcpyDeviceToHost));
+    if (ply) *ply = c.ply;
+    if (sim) *sim = c.sim;
+    if (status) *status = c.status;
+    if (game_id) *game_id = c.game_id;
+    if (last_path_len) *last_path_len = c.path_len;
+    if (last_path && c.path_len > 0)
+        HIPOK(hipMemcpy(last_path, sp->p.path + (size_t)slot * sp->p.max_depth, (size_t)std::min(c.path_len, 1024) * 4,
+                        hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int sc_selfplay_set_noise(sc_selfplay* sp, int slot, const float* noise, int n) {
+    if (!sp || slot < 0 || slot >= sp->p.n_slots || n < 0 || n > 224) return fail("bad argument");
+    HIPOK(hipSetDevice(sp->device));
+    HIPOK(hipStreamSynchronize(sp->stream));
+    HIPOK(hipMemcpy(sp->p.noise + (size_t)slot * 224, noise, (size_t)n * 4, hipMemcpyHostToDevice));
+    return 0;
+}
+int sc_selfplay_get_noise(sc_selfplay* sp, int slot, float* noise, int cap) {
+    if (!sp || slot < 0 || slot >= sp->p.n_slots) return fail("bad argument");
+    HIPOK(hipSetDevice(sp->device));
+    HIPOK(hipStreamSynchronize(sp->stream));
+    HIPOK(hipMemcpy(noise, sp->p.noise + (size_t)slot * 224, (size_t)std::min(cap, 224) * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int sc_selfplay_set_position(sc_selfplay* sp, int slot, const uint16_t* moves, int n_moves) {
+    if (!sp || slot < 0 || slot >= sp->p.n_slots || n_moves < 0 || n_moves > 590) return fail("bad argument");
+    HIPOK(hipSetDevice(sp->device));
+    uint16_t* d_moves = nullptr;
+    HIPOK(dalloc(&d_moves, (size_t)n_moves));
+    if (n_moves) HIPOK(hipMemcpy(d_moves, moves, (size_t)n_moves * 2, hipMemcpyHostToDevice));
+    scl::set_position(sp->p, slot, d_moves, n_moves, sp->stream);
+    HIPOK(hipGetLastError());
+    HIPOK(hipStreamSynchronize(sp->stream));
+    (void)hipFree(d_moves);
+    return 0;
+}
+
+int sc_move_uci(uint16_t move, char* buf8) { return sctrace::move_uci(move, buf8); }
+
+}  // extern "C"

@@ -1,0 +1,24 @@
+// launchers.hpp -- host entry points of the two kernel translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "mcts_types.hpp"
+#include "nn_types.hpp"
+
+namespace scl {
+// mcts_kernels.hip (compiled with -ffp-contract=off)
+void init_slots(const sc::SpParams& p, hipStream_t s);
+void select(const sc::SpParams& p, hipStream_t s);
+void synth_eval(const sc::SpParams& p, hipStream_t s);
+void expand_backup(const sc::SpParams& p, hipStream_t s);
+void set_position(const sc::SpParams& p, int slot, const uint16_t* d_moves, int n_moves, hipStream_t s);
+void encode_positions(int n_pos, const uint16_t* d_moves, const uint32_t* d_move_off, sc::Position* d_hist, int hist_cap,
+                      int8_t* boards, int32_t* meta, uint16_t* legal_mv, uint16_t* legal_idx, int32_t* n_legal,
+                      int32_t* outcome, hipStream_t s);
+// nn_kernels.hip
+const char* nn_init();  // sets kernel attributes; returns error text or nullptr
+size_t tower_lds_bytes(int C);
+void tower(const scnn::TowerArgs& a, hipStream_t s);
+void value_fc1(const scnn::Fc1Args& a, hipStream_t s);
+void value_finish(const scnn::VfinArgs& a, hipStream_t s);
+}  // namespace scl

@@ -1,0 +1,21 @@
+// mcts_kernels.hip -- translation unit of the search kernels.  Build with -ffp-contract=off
+// (exact f32 PUCT arithmetic, see mcts_kernels.hpp).
+#include "mcts_kernels.hpp"
+
+#include "launchers.hpp"
+
+namespace scl {
+void init_slots(const sc::SpParams& p, hipStream_t s) { hipLaunchKernelGGL(sc::k_init_slots, dim3(p.n_slots), dim3(64), 0, s, p); }
+void select(const sc::SpParams& p, hipStream_t s) { hipLaunchKernelGGL(sc::k_select, dim3(p.n_slots), dim3(64), 0, s, p); }
+void synth_eval(const sc::SpParams& p, hipStream_t s) { hipLaunchKernelGGL(sc::k_synth_eval, dim3(p.n_slots), dim3(64), 0, s, p); }
+void expand_backup(const sc::SpParams& p, hipStream_t s) { hipLaunchKernelGGL(sc::k_expand_backup, dim3(p.n_slots), dim3(64), 0, s, p); }
+void set_position(const sc::SpParams& p, int slot, const uint16_t* d_moves, int n_moves, hipStream_t s) {
+    hipLaunchKernelGGL(sc::k_set_position, dim3(1), dim3(64), 0, s, p, slot, d_moves, n_moves);
+}
+void encode_positions(int n_pos, const uint16_t* d_moves, const uint32_t* d_move_off, sc::Position* d_hist, int hist_cap,
+                      int8_t* boards, int32_t* meta, uint16_t* legal_mv, uint16_t* legal_idx, int32_t* n_legal,
+                      int32_t* outcome, hipStream_t s) {
+    hipLaunchKernelGGL(sc::k_encode_positions, dim3(n_pos), dim3(64), 0, s, n_pos, d_moves, d_move_off, d_hist, hist_cap,
+                       boards, meta, legal_mv, legal_idx, n_legal, outcome);
+}
+}  // namespace scl

@@ -1,0 +1,749 @@
+// mcts_kernels.hpp -- PUCT search on the GPU: one 64-lane wavefront per concurrent game.
+//
+// Rewrites src/mcts.rs (Node/Cursor/uct/find_max/backward/select/mcts/step), the Game::predict
+// front half (legal moves, terminal test, _encode: src/backends/torch.rs:89-113, src/chess.rs:845-877)
+// and the per-ply driver of src/main.rs:168-233 as HIP kernels.
+//
+// Data layout in HBM (per game slot g; all arrays are contiguous per slot so one wave's accesses
+// coalesce): SoA node pool N/W/P/U/MV/NC/FC/PS[g*node_cap + i] with the children of a node stored
+// contiguously in python-chess move order (lane = child in PUCT), Position records for the game
+// line (hist) and for expanded nodes (tpos), the last path, and the NN input/outputs of the leaf.
+// Priors are cached at expansion (the reference re-evaluates the net at every node of every
+// descent, src/mcts.rs:152; the net is deterministic so the search is identical).
+//
+// Scalar chess logic (make_move, move generation) is executed wave-uniformly (all lanes compute
+// the same values: no divergence, no broadcasts); PUCT argmax, repetition scan, plane encoding,
+// child initialisation and backup are lane-parallel with wave shuffles/ballots.
+//
+// This translation unit is compiled with -ffp-contract=off: the PUCT arithmetic must round
+// exactly like the reference's f32 expression (src/mcts.rs:69-75), which Rust never contracts.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "chess_history.hpp"
+#include "mcts_types.hpp"
+
+namespace sc {
+
+// ------------------------------------------------------------------ wave helpers (64 lanes)
+__device__ inline int wave_sum_i(int v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ inline float wave_sum_f(float v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ inline unsigned long long wave_sum_u64(unsigned long long v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// chain of positions: game history, then the tree path, then the leaf being created
+struct DevChain {
+    const Position* hist;
+    int root_ply;
+    const Position* tpos;
+    const uint16_t* PS;      // node -> tpos slot (slot-local pool)
+    const int32_t* path;     // path[d] = node at depth d
+    const Position* leaf;
+    int leaf_idx;
+    __device__ const Position& pos(int i) const {
+        if (i <= root_ply) return hist[i];
+        if (i == leaf_idx) return *leaf;
+        return tpos[PS[path[i - root_ply]]];
+    }
+};
+struct HistChain {
+    const Position* hist;
+    __device__ const Position& pos(int i) const { return hist[i]; }
+};
+
+// is_repetition(2) / is_repetition(3) of the position at chain index idx, lane-parallel.
+// Lane L looks at i = idx-L: the walk of python-chess is_repetition stops at the first i whose
+// incoming move was irreversible, and compares pos(i-1) otherwise.
+template <class Chain>
+__device__ inline uint8_t rep_flags_wave(const Chain& ch, int idx, bb_t key0, int lane) {
+    int matches = 0;
+    for (int base = 0;; base += 64) {
+        int i = idx - base - lane;
+        bool valid = i >= 1;
+        bool irrev = false, match = false;
+        if (valid) {
+            irrev = (ch.pos(i).flags & F_IRREV) != 0;
+            match = ch.pos(i - 1).key == key0;
+        }
+        unsigned long long stopmask = __ballot(irrev || !valid);
+        unsigned long long matchmask = __ballot(match && valid);
+        bool stopped = stopmask != 0;
+        if (stopped) {
+            int first = __ffsll((long long)stopmask) - 1;
+            matchmask &= first == 0 ? 0ULL : (~0ULL >> (64 - first));
+        }
+        matches += __popcll(matchmask);
+        if (stopped || matches >= 2) break;
+    }
+    return (uint8_t)((matches >= 1 ? F_REP2 : 0) | (matches >= 2 ? F_REP3 : 0));
+}
+
+// _encode (src/chess.rs:845-877) for the position at chain index idx: lane = output pixel.
+// stage: 7168 B of LDS; out: int8[64][112] in HBM.
+template <class Chain>
+__device__ inline void encode_wave(const Chain& ch, int idx, int lane, int8_t* stage, int8_t* out, int32_t* meta_out) {
+    uint4* cell16 = reinterpret_cast<uint4*>(stage + lane * 112);
+#pragma unroll
+    for (int k = 0; k < 7; k++) cell16[k] = make_uint4(0, 0, 0, 0);
+    int8_t* cell = stage + lane * 112;
+    const Position& cur = ch.pos(idx);
+    int turn = cur.turn;
+    int src = turn == BLACK ? (lane ^ 56) : lane;
+    bb_t sb = bit(src);
+    for (int j = 0; j < 8 && j <= idx; j++) {
+        const Position& h = ch.pos(idx - j);
+        bb_t ow = h.occ[WHITE], ob = h.occ[BLACK];
+        if ((ow | ob) & sb) {
+            int t = 0;
+#pragma unroll
+            for (int k = 1; k < 6; k++)
+                if (h.pcs[k] & sb) t = k;
+            int is_white = (ow & sb) ? 1 : 0;
+            int mover_side = turn == BLACK ? !is_white : is_white;
+            cell[14 * j + t + (mover_side ? 0 : 6)] = 1;
+        }
+        uint8_t f = h.flags;
+        cell[14 * j + 12] = (f & F_REP2) ? 1 : 0;
+        cell[14 * j + 13] = (f & F_REP3) ? 1 : 0;
+    }
+    uint4* o16 = reinterpret_cast<uint4*>(out + lane * 112);
+#pragma unroll
+    for (int k = 0; k < 7; k++) o16[k] = cell16[k];
+    if (lane == 0) {
+        int32_t m[7];
+        encode_meta(cur, m);
+#pragma unroll
+        for (int k = 0; k < 7; k++) meta_out[k] = m[k];
+        meta_out[7] = 0;
+    }
+}
+
+// ------------------------------------------------------------------ Dirichlet(0.3) root noise
+// get_noise (src/mcts.rs:123-130).  The reference draws from thread_rng; here a counter-based
+// stream keyed by (seed, game, ply, sim, child) -- parity is distributional only.
+__device__ inline float u01_open(uint64_t& st) {
+    st = mix64(st);
+    return ((float)(st >> 40) + 0.5f) * (1.0f / 16777216.0f);
+}
+__device__ inline float gamma03(uint64_t st) {
+    const float alpha = 0.3f;
+    float boost = powf(u01_open(st), 1.0f / alpha);
+    const float d = alpha + 1.0f - 1.0f / 3.0f;
+    const float c = 1.0f / sqrtf(9.0f * d);
+    for (int it = 0; it < 64; it++) {
+        float a = u01_open(st), b = u01_open(st);
+        float x = sqrtf(-2.0f * logf(a)) * cosf(6.2831853f * b);
+        float v = 1.0f + c * x;
+        if (v <= 0.0f) continue;
+        v = v * v * v;
+        float u = u01_open(st);
+        if (logf(u) < 0.5f * x * x + d - d * v + d * logf(v)) return boost * d * v;
+    }
+    return boost * d;
+}
+
+// ------------------------------------------------------------------ select (src/mcts.rs:132-227)
+__global__ __launch_bounds__(64) void k_select(SpParams p) {
+    const int g = blockIdx.x, lane = threadIdx.x;
+    __shared__ __attribute__((aligned(16))) int8_t s_stage[7168];
+    __shared__ move_t s_moves[MAXC];
+    __shared__ Position s_leaf;
+    GameCtl& c = p.ctl[g];
+    if (c.status != ST_ACTIVE) {
+        if (lane == 0) c.leaf_kind = LK_NONE;
+        return;
+    }
+    const size_t nb = (size_t)g * p.node_cap;
+    int32_t* N = p.N + nb;
+    float* W = p.W + nb;
+    float* P = p.P + nb;
+    float* U = p.U + nb;
+    uint16_t* MV = p.MV + nb;
+    uint16_t* NC = p.NC + nb;
+    int32_t* FC = p.FC + nb;
+    uint16_t* PS = p.PS + nb;
+    int32_t* path = p.path + (size_t)g * p.max_depth;
+    const Position* hist = p.hist + (size_t)g * p.hist_cap;
+    Position* tpos = p.tpos + (size_t)g * p.tpos_cap;
+    const int root_ply = c.ply;
+    const int root_turn = hist[root_ply].turn;
+
+    int node = 0, depth = 0;
+    if (lane == 0) path[0] = 0;
+    uint32_t err = 0;
+    for (;;) {
+        int nc = NC[node];
+        if (nc == 0) break;
+        int fc = FC[node];
+        int child;
+        if (nc == 1) {
+            child = fc;
+        } else {
+            // side to move at `node`: root_turn flipped per depth; reverse_q = Black to move (torch.rs:49-52)
+            bool reverse_q = ((root_turn ^ (depth & 1)) == BLACK);
+            bool noisy = depth == 0 && p.with_noise;
+            float* nz = p.noise + (size_t)g * MAXC;
+            if (noisy && !p.external_noise) {
+                float gsum = 0.0f;
+                float gv[4];
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    int i = lane + 64 * r;
+                    gv[r] = 0.0f;
+                    if (i < nc) {
+                        gv[r] = gamma03(sc_rng(p.seed, c.game_id, (uint64_t)root_ply, 3, (uint64_t)c.sim * 256 + (uint64_t)i));
+                        gsum += gv[r];
+                    }
+                }
+                gsum = wave_sum_f(gsum);
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    int i = lane + 64 * r;
+                    if (i < nc) nz[i] = gv[r] / gsum;
+                }
+            }
+            int tot = 0;
+            for (int i = lane; i < nc; i += 64) tot += N[fc + i];
+            tot = wave_sum_i(tot);
+            float sqrt_total = sqrtf((float)tot);
+            float best_u = 0.0f;
+            int best_i = -1;
+            for (int i = lane; i < nc; i += 64) {
+                float prior = P[fc + i];
+                if (noisy) prior = prior * (1.0f - p.epsilon) + nz[i] * p.epsilon;  // mcts.rs:181
+                int n = N[fc + i];
+                float q = W[fc + i];
+                // uct(): src/mcts.rs:69-75
+                float average_award = q / ((float)n + 1e-4f) * (reverse_q ? -1.0f : 1.0f);
+                float exploration = (sqrt_total + 0.01f) / (1.0f + (float)n) * p.cpuct * prior;
+                float u = average_award + exploration;
+                U[fc + i] = u;
+                if (!isfinite(u)) err |= ERR_NONFINITE_UCT;
+                if (best_i < 0 || u >= best_u) {  // later index wins ties (max_by keeps the last maximum)
+                    best_u = u;
+                    best_i = i;
+                }
+            }
+            for (int o = 32; o > 0; o >>= 1) {
+                float ou = __shfl_xor(best_u, o, 64);
+                int oi = __shfl_xor(best_i, o, 64);
+                bool take = oi >= 0 && (best_i < 0 || ou > best_u || (ou == best_u && oi > best_i));
+                if (take) {
+                    best_u = ou;
+                    best_i = oi;
+                }
+            }
+            child = fc + best_i;
+        }
+        node = child;
+        depth++;
+        if (depth >= p.max_depth) {
+            err |= ERR_DEPTH_OVERFLOW;
+            depth--;
+            break;
+        }
+        if (lane == 0) path[depth] = node;
+    }
+    unsigned long long anyerr = __ballot(err != 0);
+    if (anyerr) {
+        for (int o = 32; o > 0; o >>= 1) err |= __shfl_xor(err, o, 64);
+        if (lane == 0) {
+            c.err |= err;
+            atomicOr(&p.cnt->err, (int)err);
+        }
+    }
+    __syncthreads();  // path[] visible to all lanes
+
+    int fcl = FC[node];
+    if (lane == 0) {
+        c.leaf = node;
+        c.path_len = depth + 1;
+    }
+    if (fcl <= -2) {  // terminal seen before: predict() returns the same outcome again (torch.rs:98-106)
+        if (lane == 0) {
+            c.leaf_kind = LK_TERM_CACHED;
+            c.leaf_value = fcl == -2 ? 0.0f : fcl == -3 ? 1.0f : -1.0f;
+            c.n_legal = 0;
+        }
+        return;
+    }
+    // position of the leaf (wave-uniform)
+    Position pos;
+    if (depth == 0) {
+        pos = tpos[0];
+    } else {
+        pos = tpos[PS[path[depth - 1]]];
+        make_move(pos, MV[node]);  // state.advance (mcts.rs:224)
+    }
+    if (lane == 0) s_leaf = pos;
+    __syncthreads();
+    DevChain ch{hist, root_ply, tpos, PS, path, &s_leaf, root_ply + depth};
+    if (depth > 0) {
+        uint8_t rf = rep_flags_wave(ch, root_ply + depth, pos.key, lane);
+        pos.flags = (uint8_t)((pos.flags & F_IRREV) | rf);
+        __syncthreads();
+        if (lane == 0) s_leaf.flags = pos.flags;
+        __syncthreads();
+    }
+    // scratch slot for the expansion (claimed in k_expand_backup if the leaf is not terminal)
+    if (lane == 0) tpos[c.n_exp] = pos;
+    MoveList ml{s_moves, 0};
+    bool in_check = gen_legal(pos, ml);
+    __syncthreads();
+    int n = ml.n;
+    if (n == 0) {
+        if (lane == 0) {
+            c.leaf_kind = LK_TERM_NEW;
+            // winner -> +1 white / -1 black / 0 (torch.rs:100-104); checkmated side is the one to move
+            c.leaf_value = in_check ? (pos.turn == WHITE ? -1.0f : 1.0f) : 0.0f;
+            c.n_legal = 0;
+        }
+        return;
+    }
+    uint16_t* lm = p.legal_mv + (size_t)g * MAXC;
+    uint16_t* li = p.legal_idx + (size_t)g * MAXC;
+    uint32_t bad = 0;
+    for (int i = lane; i < n; i += 64) {
+        move_t m = s_moves[i];
+        int idx = move_index(m, pos.turn);
+        if (idx < 0) {
+            bad = 1;
+            idx = 0;
+        }
+        lm[i] = m;
+        li[i] = (uint16_t)idx;
+    }
+    if (__ballot(bad) && lane == 0) {
+        c.err |= ERR_BAD_MOVE_INDEX;
+        atomicOr(&p.cnt->err, ERR_BAD_MOVE_INDEX);
+    }
+    encode_wave(ch, root_ply + depth, lane, s_stage, p.boards + (size_t)g * 7168, p.meta + (size_t)g * 8);
+    if (lane == 0) {
+        c.leaf_kind = LK_EVAL;
+        c.n_legal = n;
+        p.n_legal[g] = n;
+    }
+}
+
+// ------------------------------------------------------------------ synthetic evaluator (tests)
+__global__ __launch_bounds__(64) void k_synth_eval(SpParams p) {
+    const int g = blockIdx.x, lane = threadIdx.x;
+    GameCtl& c = p.ctl[g];
+    if (c.status != ST_ACTIVE || c.leaf_kind != LK_EVAL) return;
+    const Position& pos = p.tpos[(size_t)g * p.tpos_cap + c.n_exp];
+    uint64_t h = synth_pos_hash(pos);
+    int n = c.n_legal;
+    const uint16_t* lm = p.legal_mv + (size_t)g * MAXC;
+    unsigned long long sum = 0;
+    for (int i = lane; i < n; i += 64) sum += synth_weight(h, lm[i]);
+    sum = wave_sum_u64(sum);
+    float fs = (float)sum;
+    for (int i = lane; i < n; i += 64) p.prior[(size_t)g * MAXC + i] = (float)synth_weight(h, lm[i]) / fs;
+    if (lane == 0) p.value[g] = synth_value(h);
+}
+
+// ------------------------------------------------------------------ game (re)start
+__device__ inline void start_new_game(SpParams& p, int g, int lane) {
+    GameCtl& c = p.ctl[g];
+    unsigned long long k = 0;
+    if (lane == 0) k = atomicAdd(&p.cnt->next_game, 1ULL);
+    k = __shfl(k, 0, 64);
+    if (k >= (unsigned long long)p.total_games) {
+        if (lane == 0) {
+            c.status = ST_IDLE;
+            c.leaf_kind = LK_NONE;
+        }
+        return;
+    }
+    const size_t nb = (size_t)g * p.node_cap;
+    if (lane == 0) {
+        Position s;
+        set_startpos(s);
+        s.key = position_key(s);
+        p.hist[(size_t)g * p.hist_cap] = s;
+        p.tpos[(size_t)g * p.tpos_cap] = s;
+        p.N[nb] = 0;
+        p.W[nb] = 0.0f;
+        p.P[nb] = 0.0f;
+        p.U[nb] = 0.0f;
+        p.MV[nb] = 0;
+        p.NC[nb] = 0;
+        p.FC[nb] = -1;
+        p.PS[nb] = 0;
+        c.status = ST_ACTIVE;
+        c.ply = 0;
+        c.start_ply = 0;
+        c.sim = 0;
+        c.n_nodes = 1;
+        c.n_exp = 1;
+        c.leaf = 0;
+        c.path_len = 0;
+        c.leaf_kind = LK_NONE;
+        c.n_legal = 0;
+        c.err = 0;
+        c.game_id = p.first_game_id + k;
+        c.trace_slot = (int32_t)(k % (unsigned long long)p.trace_cap);
+        TraceHdr& th = p.thdr[c.trace_slot];
+        th.n_steps = 0;
+        th.has_outcome = 0;
+        th.termination = 0;
+        th.winner = -1;
+        th.game_id = c.game_id;
+        th.done = 0;
+    }
+}
+__global__ __launch_bounds__(64) void k_init_slots(SpParams p) {
+    const int g = blockIdx.x, lane = threadIdx.x;
+    uint4* b = reinterpret_cast<uint4*>(p.boards + (size_t)g * 7168);
+    for (int i = lane; i < 448; i += 64) b[i] = make_uint4(0, 0, 0, 0);
+    if (lane < 8) p.meta[(size_t)g * 8 + lane] = 0;
+    if (lane == 0) p.n_legal[g] = 0;
+    start_new_game(p, g, lane);
+}
+
+__device__ inline void finish_game(SpParams& p, int g, int lane, int has_outcome, int term, int winner) {
+    GameCtl& c = p.ctl[g];
+    if (lane == 0) {
+        TraceHdr& th = p.thdr[c.trace_slot];
+        th.n_steps = c.ply - c.start_ply;
+        th.has_outcome = has_outcome;
+        th.termination = term;
+        th.winner = winner;
+        th.game_id = c.game_id;
+        __threadfence();
+        th.done = 1;
+        atomicAdd(&p.cnt->games_finished, 1);
+        c.status = ST_FINISHED;
+    }
+    __syncthreads();
+    start_new_game(p, g, lane);
+}
+
+// ------------------------------------------------------------------ expand + backward + mcts::step
+// mcts.rs:267-288 (expand, backward), then when the rollout count is reached the per-ply part of
+// src/main.rs:198-233: snapshot root/children into the trace, mcts::step (mcts.rs:292-328), outcome.
+__global__ __launch_bounds__(64) void k_expand_backup(SpParams p) {
+    const int g = blockIdx.x, lane = threadIdx.x;
+    GameCtl& c = p.ctl[g];
+    if (c.status != ST_ACTIVE || c.leaf_kind == LK_NONE) return;
+    const size_t nb = (size_t)g * p.node_cap;
+    int32_t* N = p.N + nb;
+    float* W = p.W + nb;
+    float* P = p.P + nb;
+    float* U = p.U + nb;
+    uint16_t* MV = p.MV + nb;
+    uint16_t* NC = p.NC + nb;
+    int32_t* FC = p.FC + nb;
+    uint16_t* PS = p.PS + nb;
+    const int32_t* path = p.path + (size_t)g * p.max_depth;
+    Position* hist = p.hist + (size_t)g * p.hist_cap;
+    Position* tpos = p.tpos + (size_t)g * p.tpos_cap;
+
+    const int leaf = c.leaf, kind = c.leaf_kind, plen = c.path_len;
+    float value = c.leaf_value;
+    int n_nodes = c.n_nodes, n_exp = c.n_exp;
+    uint32_t err = 0;
+    if (kind == LK_EVAL) {
+        value = p.value[g];
+        int n = c.n_legal;
+        if (n_nodes + n > p.node_cap || n_exp + 1 >= p.tpos_cap) {
+            err = ERR_POOL_OVERFLOW;
+        } else {
+            const uint16_t* lm = p.legal_mv + (size_t)g * MAXC;
+            const float* pr = p.prior + (size_t)g * MAXC;
+            for (int i = lane; i < n; i += 64) {
+                int id = n_nodes + i;
+                N[id] = 0;
+                W[id] = 0.0f;
+                P[id] = pr[i];
+                U[id] = 0.0f;
+                MV[id] = lm[i];
+                NC[id] = 0;
+                FC[id] = -1;
+                PS[id] = 0;
+            }
+            if (lane == 0) {
+                FC[leaf] = n_nodes;
+                NC[leaf] = (uint16_t)n;
+                PS[leaf] = (uint16_t)n_exp;
+            }
+            n_nodes += n;
+            n_exp += 1;
+        }
+    } else if (kind == LK_TERM_NEW) {
+        if (lane == 0) FC[leaf] = value == 0.0f ? -2 : value > 0.0f ? -3 : -4;
+    }
+    // backward (mcts.rs:90-98): every node of the path, root included
+    for (int d = lane; d < plen; d += 64) {
+        int nd = path[d];
+        N[nd] += 1;
+        W[nd] += value;
+    }
+    __syncthreads();
+    int sim = c.sim + 1;
+    if (lane == 0) {
+        c.n_nodes = n_nodes;
+        c.n_exp = n_exp;
+        c.sim = sim;
+        c.leaf_kind = LK_NONE;
+        if (err) {
+            c.err |= err;
+            atomicOr(&p.cnt->err, (int)err);
+        }
+        atomicAdd(&p.cnt->sims_done, 1ULL);
+        if (kind == LK_EVAL) atomicAdd(&p.cnt->nn_evals, 1ULL);
+    }
+    if (sim < p.rollout) return;
+
+    // ---------------- end of this ply's search (main.rs:198-233)
+    __threadfence_block();
+    __syncthreads();
+    const int ply = c.ply;
+    const int nc = NC[0], fc = FC[0];
+    if (nc == 0) {
+        // mcts::step -> None: no children => no legal moves (main.rs:213-216)
+        HistChain hc{hist};
+        int winner = -1;
+        int term = outcome_claim_draw(hc, ply, &winner);
+        finish_game(p, g, lane, term != T_NONE, term, winner);
+        return;
+    }
+    const int ts = c.trace_slot;
+    const size_t tstep = (size_t)ts * p.num_steps + (size_t)(ply - c.start_ply);
+    for (int i = lane; i < nc; i += 64) {
+        p.t_cmove[tstep * MAXC + i] = MV[fc + i];
+        p.t_cn[tstep * MAXC + i] = N[fc + i];
+        p.t_cq[tstep * MAXC + i] = W[fc + i];
+        p.t_cu[tstep * MAXC + i] = U[fc + i];
+    }
+    // mcts::step (mcts.rs:298-317)
+    float temperature = (ply - c.start_ply) < p.temp_switch ? 1.0f : p.temperature;
+    int choice = 0;
+    if (temperature == 0.0f) {
+        int bn = -1, bi = 0x7fffffff;
+        for (int i = lane; i < nc; i += 64) {
+            int n = N[fc + i];
+            if (n > bn) {  // first maximum within the lane (indices increase)
+                bn = n;
+                bi = i;
+            }
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            int on = __shfl_xor(bn, o, 64), oi = __shfl_xor(bi, o, 64);
+            if (on > bn || (on == bn && oi < bi)) {
+                bn = on;
+                bi = oi;
+            }
+        }
+        choice = bi;
+    } else {
+        // WeightedIndex over N^(1/temp): sequential f32 cumulative sums, x = u*total,
+        // index = number of cumulative weights (last excluded) <= x
+        float power = 1.0f / temperature;
+        float total = 0.0f;
+        for (int i = 0; i < nc; i++) {
+            float n = (float)N[fc + i];
+            total += power == 1.0f ? n : powf(n, power);
+        }
+        float u = (float)(sc_rng(p.seed, c.game_id, (uint64_t)ply, 1, 0) >> 40) / 16777216.0f;
+        float x = u * total;
+        float cum = 0.0f;
+        int idx = 0;
+        for (int i = 0; i < nc - 1; i++) {
+            float n = (float)N[fc + i];
+            cum += power == 1.0f ? n : powf(n, power);
+            if (cum <= x) idx++;
+        }
+        choice = idx;
+    }
+    move_t mv = MV[fc + choice];
+    if (lane == 0) {
+        p.t_move[tstep] = mv;
+        p.t_q[tstep] = W[0];
+        p.t_nchild[tstep] = nc;
+    }
+    // advance the game line
+    Position np = hist[ply];
+    make_move(np, mv);
+    __shared__ Position s_np;
+    if (lane == 0) s_np = np;
+    __syncthreads();
+    {
+        DevChain ch{hist, ply, tpos, PS, path, &s_np, ply + 1};
+        uint8_t rf = rep_flags_wave(ch, ply + 1, np.key, lane);
+        np.flags = (uint8_t)((np.flags & F_IRREV) | rf);
+    }
+    __syncthreads();
+    if (lane == 0) {
+        hist[ply + 1] = np;
+        atomicAdd(&p.cnt->plies_done, 1ULL);
+    }
+    __threadfence_block();
+    __syncthreads();
+    const int new_ply = ply + 1;
+    if (lane == 0) c.ply = new_ply;
+    const int i_step = ply - c.start_ply;  // the reference's loop index i
+    if (i_step > p.outcome_gate) {         // main.rs:223-228
+        HistChain hc{hist};
+        int winner = -1;
+        int term = outcome_claim_draw(hc, new_ply, &winner);
+        if (term != T_NONE) {
+            __syncthreads();
+            finish_game(p, g, lane, 1, term, winner);
+            return;
+        }
+    }
+    if (i_step + 1 >= p.num_steps || new_ply + 1 >= p.hist_cap) {  // loop ends: outcome stays null
+        __syncthreads();
+        finish_game(p, g, lane, 0, 0, -1);
+        return;
+    }
+    // fresh search tree rooted at the new position (chosen child is reset(), mcts.rs:319-323)
+    if (lane == 0) {
+        tpos[0] = np;
+        N[0] = 0;
+        W[0] = 0.0f;
+        P[0] = 0.0f;
+        U[0] = 0.0f;
+        MV[0] = mv;
+        NC[0] = 0;
+        FC[0] = -1;
+        PS[0] = 0;
+        c.n_nodes = 1;
+        c.n_exp = 1;
+        c.sim = 0;
+    }
+}
+
+// ------------------------------------------------------------------ sc_selfplay_set_position
+__global__ __launch_bounds__(64) void k_set_position(SpParams p, int g, const uint16_t* moves, int n_moves) {
+    const int lane = threadIdx.x;
+    GameCtl& c = p.ctl[g];
+    Position* hist = p.hist + (size_t)g * p.hist_cap;
+    Position* tpos = p.tpos + (size_t)g * p.tpos_cap;
+    __shared__ Position s_np;
+    Position cur;
+    set_startpos(cur);
+    cur.key = position_key(cur);
+    if (lane == 0) hist[0] = cur;
+    __syncthreads();
+    for (int i = 0; i < n_moves && i + 1 < p.hist_cap; i++) {
+        make_move(cur, moves[i]);
+        if (lane == 0) s_np = cur;
+        __syncthreads();
+        DevChain ch{hist, i, tpos, p.PS, p.path, &s_np, i + 1};
+        uint8_t rf = rep_flags_wave(ch, i + 1, cur.key, lane);
+        cur.flags = (uint8_t)((cur.flags & F_IRREV) | rf);
+        __syncthreads();
+        if (lane == 0) hist[i + 1] = cur;
+        __threadfence_block();
+        __syncthreads();
+    }
+    if (lane == 0) {
+        const size_t nb = (size_t)g * p.node_cap;
+        tpos[0] = cur;
+        p.N[nb] = 0;
+        p.W[nb] = 0.0f;
+        p.NC[nb] = 0;
+        p.FC[nb] = -1;
+        p.PS[nb] = 0;
+        c.ply = n_moves;
+        c.start_ply = n_moves;
+        c.sim = 0;
+        c.n_nodes = 1;
+        c.n_exp = 1;
+        c.leaf_kind = LK_NONE;
+        c.status = ST_ACTIVE;
+    }
+}
+
+// ------------------------------------------------------------------ sc_encode_positions
+// One wave per position: replay the move list from the start position (validating every move
+// against the legal-move generator), then produce the NN input, the legal moves + action indices
+// and outcome(claim_draw=True).  hist scratch: [n][hist_cap] Positions.
+__global__ __launch_bounds__(64) void k_encode_positions(int n_pos, const uint16_t* moves, const uint32_t* move_off,
+                                                         Position* hist_all, int hist_cap, int8_t* boards, int32_t* meta,
+                                                         uint16_t* legal_mv, uint16_t* legal_idx, int32_t* n_legal,
+                                                         int32_t* outcome) {
+    const int g = blockIdx.x, lane = threadIdx.x;
+    if (g >= n_pos) return;
+    __shared__ __attribute__((aligned(16))) int8_t s_stage[7168];
+    __shared__ move_t s_moves[MAXC];
+    __shared__ Position s_np;
+    Position* hist = hist_all + (size_t)g * hist_cap;
+    const uint16_t* mv = moves + move_off[g];
+    int nm = (int)(move_off[g + 1] - move_off[g]);
+    Position cur;
+    set_startpos(cur);
+    cur.key = position_key(cur);
+    if (lane == 0) hist[0] = cur;
+    __syncthreads();
+    int status = 0;
+    int played = 0;
+    for (int i = 0; i < nm && i + 1 < hist_cap; i++) {
+        MoveList ml{s_moves, 0};
+        gen_legal(cur, ml);
+        __syncthreads();
+        bool found = false;
+        for (int k = 0; k < ml.n; k++)
+            if (s_moves[k] == mv[i]) found = true;
+        __syncthreads();
+        if (!found) {
+            status = -(i + 1);
+            break;
+        }
+        make_move(cur, mv[i]);
+        if (lane == 0) s_np = cur;
+        __syncthreads();
+        DevChain ch{hist, i, hist, nullptr, nullptr, &s_np, i + 1};
+        uint8_t rf = rep_flags_wave(ch, i + 1, cur.key, lane);
+        cur.flags = (uint8_t)((cur.flags & F_IRREV) | rf);
+        __syncthreads();
+        if (lane == 0) hist[i + 1] = cur;
+        __threadfence_block();
+        __syncthreads();
+        played = i + 1;
+    }
+    HistChain hc{hist};
+    MoveList ml{s_moves, 0};
+    bool in_check = gen_legal(cur, ml);
+    __syncthreads();
+    int n = ml.n;
+    if (legal_mv)
+        for (int i = lane; i < n; i += 64) legal_mv[(size_t)g * MAXC + i] = s_moves[i];
+    if (legal_idx)
+        for (int i = lane; i < n; i += 64) legal_idx[(size_t)g * MAXC + i] = (uint16_t)move_index(s_moves[i], cur.turn);
+    if (n_legal && lane == 0) n_legal[g] = n;
+    if (boards) {
+        int32_t mtmp_dummy[8];
+        (void)mtmp_dummy;
+        __shared__ int32_t s_meta[8];
+        encode_wave(hc, played, lane, s_stage, boards + (size_t)g * 7168, s_meta);
+        __syncthreads();
+        if (meta && lane < 7) meta[(size_t)g * 7 + lane] = s_meta[lane];
+    } else if (meta && lane == 0) {
+        int32_t m[7];
+        encode_meta(cur, m);
+        for (int k = 0; k < 7; k++) meta[(size_t)g * 7 + k] = m[k];
+    }
+    if (outcome) {
+        int winner = -1;
+        int term = outcome_claim_draw(hc, played, &winner);
+        if (lane == 0) {
+            outcome[(size_t)g * 4 + 0] = term;
+            outcome[(size_t)g * 4 + 1] = winner;
+            outcome[(size_t)g * 4 + 2] = in_check ? 1 : 0;
+            outcome[(size_t)g * 4 + 3] = status;
+        }
+    }
+}
+
+}  // namespace sc

@@ -1,0 +1,73 @@
+// mcts_types.hpp -- device-resident state of the self-play engine (shared by host code and kernels).
+#pragma once
+#include <stdint.h>
+
+#include "chess_rules.hpp"
+
+namespace sc {
+
+constexpr int MAXC = 224;  // SC_MAX_MOVES
+enum { ST_IDLE = 0, ST_ACTIVE = 1, ST_FINISHED = 2 };
+enum { LK_NONE = 0, LK_EVAL = 1, LK_TERM_NEW = 2, LK_TERM_CACHED = 3 };
+enum { ERR_NONFINITE_UCT = 1, ERR_POOL_OVERFLOW = 2, ERR_BAD_MOVE_INDEX = 4, ERR_DEPTH_OVERFLOW = 8 };
+
+struct GameCtl {
+    int32_t status, ply, sim, n_nodes, n_exp;
+    int32_t leaf, path_len, leaf_kind, n_legal;
+    float leaf_value;
+    uint32_t err;
+    int32_t trace_slot;
+    uint64_t game_id;
+    int32_t start_ply;  // ply index at which this slot's game started searching (sc_selfplay_set_position)
+    int32_t pad;
+};
+
+struct TraceHdr {
+    int32_t n_steps, has_outcome, termination, winner;
+    uint64_t game_id;
+    int32_t done, pad;
+};
+
+struct Counters {
+    unsigned long long next_game, sims_done, nn_evals, plies_done;
+    int32_t games_finished, err;
+};
+
+struct SpParams {
+    int n_slots, rollout, num_steps, temp_switch, with_noise, outcome_gate, evaluator, external_noise;
+    float cpuct, temperature, epsilon;
+    uint64_t seed, first_game_id;
+    int node_cap, max_depth, hist_cap, tpos_cap, trace_cap, total_games;
+    GameCtl* ctl;
+    Position* hist;   // [slot][hist_cap]
+    Position* tpos;   // [slot][tpos_cap]
+    int32_t* path;    // [slot][max_depth]
+    int32_t* N;
+    float* W;
+    float* P;
+    float* U;
+    uint16_t* MV;
+    uint16_t* NC;
+    int32_t* FC;      // >=0 first child; -1 unexpanded; -2/-3/-4 terminal with value 0/+1/-1
+    uint16_t* PS;     // tpos slot of an expanded node
+    int8_t* boards;   // [slot][7168]
+    int32_t* meta;    // [slot][8]
+    uint16_t* legal_mv;   // [slot][MAXC]
+    uint16_t* legal_idx;  // [slot][MAXC]
+    int32_t* n_legal;     // [slot]
+    float* prior;         // [slot][MAXC]
+    float* value;         // [slot]
+    float* noise;         // [slot][MAXC]
+    TraceHdr* thdr;       // [trace_cap]
+    uint16_t* t_move;     // [trace_cap][num_steps]
+    float* t_q;
+    int32_t* t_nchild;
+    uint16_t* t_cmove;    // [trace_cap][num_steps][MAXC]
+    int32_t* t_cn;
+    float* t_cq;
+    float* t_cu;
+    Counters* cnt;
+};
+
+
+}  // namespace sc

@@ -1,0 +1,35 @@
+// nn_kernels.hip -- translation unit of the network kernels.
+#include "nn_kernels.hpp"
+
+#include "launchers.hpp"
+
+namespace scl {
+size_t tower_lds_bytes(int C) {
+    size_t cp = (size_t)C + 8, hp = scnn::HEAD + 8;
+    return 100 * cp * 2 + 64 * hp * 2 + 512 * 4 + 640 * 4 + 8 * 4;
+}
+const char* nn_init() {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scnn::k_tower<256>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)tower_lds_bytes(256));
+    if (e != hipSuccess) return hipGetErrorString(e);
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scnn::k_tower<128>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)tower_lds_bytes(128));
+    if (e != hipSuccess) return hipGetErrorString(e);
+    return nullptr;
+}
+void tower(const scnn::TowerArgs& a, hipStream_t s) {
+    if (a.n_pos <= 0) return;
+    if (a.net.C == 256)
+        hipLaunchKernelGGL(scnn::k_tower<256>, dim3(a.n_pos), dim3(256), tower_lds_bytes(256), s, a);
+    else
+        hipLaunchKernelGGL(scnn::k_tower<128>, dim3(a.n_pos), dim3(256), tower_lds_bytes(128), s, a);
+}
+void value_fc1(const scnn::Fc1Args& a, hipStream_t s) {
+    if (a.n_pos <= 0) return;
+    hipLaunchKernelGGL(scnn::k_value_fc1, dim3((a.n_pos + 63) / 64, a.ksplit), dim3(256), 0, s, a);
+}
+void value_finish(const scnn::VfinArgs& a, hipStream_t s) {
+    if (a.n_pos <= 0) return;
+    hipLaunchKernelGGL(scnn::k_value_finish, dim3(a.n_pos), dim3(64), 0, s, a);
+}
+}  // namespace scl

@@ -1,0 +1,550 @@
+// nn_kernels.hpp -- policy/value network forward for gfx950 (MI355X), hand-written MFMA kernels.
+//
+// Reproduces ChessModule.forward (reference py/module.py:135-154; ResBlockSE :14-46, PolicyHead
+// :65-80, ValueHead :83-106) with the numerics of the exported bf16 graph the Rust backends load
+// (src/backends/torch.rs:115-125): bf16 GEMM operands, fp32 accumulate,
+// fp32 LayerNorm and residual stream, fp32 log-softmax.
+//
+// Design (MI355X-first, not a port of any library graph):
+//   * ONE workgroup (4 waves, one per SIMD) owns ONE position for the whole tower.  The position's
+//     activation never leaves the CU: a zero-haloed bf16 image [10x10 pixels][C] in LDS feeds the
+//     implicit-GEMM A operand of every 3x3 conv (M = 64 pixels), the fp32 residual stream lives in
+//     registers in MFMA accumulator layout, and LayerNorm / SE / residual / ReLU are epilogues.
+//     No activation is written to HBM between layers; per position the kernel reads 7 KB of input
+//     planes and writes 32 KB (value-head features) + <=19 KB (policy).
+//   * Weights are streamed from L2 / Infinity Cache straight into VGPRs, pre-packed on the host in
+//     v_mfma_f32_16x16x32_bf16 B-fragment order (one contiguous 1 KiB per wave-load), behind a
+//     4-step register prefetch ring.  All 256 workgroups walk the layers roughly in step, so a
+//     layer's 1.18 MB of weights is served from the XCD's L2 after the first toucher.
+//   * The N dimension is split over the 4 waves (64 output channels each for C=256) so every
+//     workgroup holds complete pixel rows: LayerNorm over channels is a 16-lane DPP/shuffle reduce
+//     plus one LDS exchange between the 4 waves.
+//   * Only the value head's Linear(16391->128) is batched ACROSS positions (its weight is 4 MB and
+//     position-specific in K): k_value_fc1 is a split-K MFMA GEMM over the whole batch, reduced in
+//     fixed order by k_value_finish (bitwise reproducible, no float atomics).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "nn_types.hpp"
+
+namespace scnn {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+__device__ inline bf16_t f2bf(float x) {
+    __bf16 b = (__bf16)x;  // v_cvt_pk_bf16_f32: round-to-nearest-even, NaN stays NaN
+    return __builtin_bit_cast(uint16_t, b);
+}
+__device__ inline float bf2f(bf16_t u) { return __builtin_bit_cast(float, (uint32_t)u << 16); }
+
+// haloed image index of pixel p (0..63)
+__device__ inline int hidx(int p) { return ((p >> 3) + 1) * 10 + (p & 7) + 1; }
+
+// --------------------------------------------------------------------------------------------
+// Implicit GEMM: acc[mt][i] += A(64 x K) * B(K x 16*NTW*4) for this wave's NTW column tiles.
+//   A: LDS image, pixel stride `CP` elements (haloed when TAPS==9, plain [64] rows when !HALO)
+//   B: global, packed [kstep][ntile_total][lane][8]
+// K = TAPS*CIN, k-step = 32.
+template <int CIN, int TAPS, int NTW, int NT_TOTAL, bool HALO>
+__device__ inline void conv_mma(const bf16_t* __restrict__ X, int CP, const bf16_t* __restrict__ Wp, int wave, int lane,
+                                f32x4 (&acc)[4][NTW]) {
+    constexpr int KPT = CIN / 32;       // k-steps per tap
+    constexpr int S = TAPS * KPT;       // total k-steps
+    static_assert(S % PF == 0, "k-steps must be a multiple of the prefetch depth");
+    const int row16 = lane & 15, kq = lane >> 4;
+    int abase[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; mt++) {
+        int p = mt * 16 + row16;
+        abase[mt] = (HALO ? hidx(p) : p) * CP + 8 * kq;
+    }
+    const bf16x8* __restrict__ Wv = reinterpret_cast<const bf16x8*>(Wp) + (size_t)(wave * NTW) * 64 + lane;
+    bf16x8 bq[PF][NTW];
+#pragma unroll
+    for (int u = 0; u < PF; u++)
+#pragma unroll
+        for (int i = 0; i < NTW; i++) bq[u][i] = Wv[((size_t)u * NT_TOTAL + i) * 64];
+#pragma unroll 1
+    for (int s0 = 0; s0 < S; s0 += PF) {
+#pragma unroll
+        for (int u = 0; u < PF; u++) {
+            const int s = s0 + u;
+            bf16x8 b[NTW];
+#pragma unroll
+            for (int i = 0; i < NTW; i++) b[i] = bq[u][i];
+            if (s + PF < S) {
+#pragma unroll
+                for (int i = 0; i < NTW; i++) bq[u][i] = Wv[((size_t)(s + PF) * NT_TOTAL + i) * 64];
+            }
+            const int tap = s / KPT, kc = s - tap * KPT;
+            const int toff = (TAPS == 9) ? ((tap / 3 - 1) * 10 + (tap % 3 - 1)) : 0;
+            const int aoff = toff * CP + kc * 32;
+            bf16x8 a[4];
+#pragma unroll
+            for (int mt = 0; mt < 4; mt++) a[mt] = *reinterpret_cast<const bf16x8*>(X + abase[mt] + aoff);
+#pragma unroll
+            for (int mt = 0; mt < 4; mt++)
+#pragma unroll
+                for (int i = 0; i < NTW; i++)
+                    acc[mt][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt], b[i], acc[mt][i], 0, 0, 0);
+        }
+    }
+}
+
+// 1 x K vector times packed B (K x 16*NTW*4): the vector sits in row 0 of the A tile.
+// x: LDS floats (rounded to bf16 on load).  Result for column tile i: lanes 0..15, element 0.
+template <int K, int NTW, int NT_TOTAL>
+__device__ inline void vec_mma(const float* x, const bf16_t* __restrict__ Wp, int wave, int lane, f32x4 (&acc)[NTW]) {
+    constexpr int S = K / 32;
+    const int row16 = lane & 15, kq = lane >> 4;
+    const bf16x8* __restrict__ Wv = reinterpret_cast<const bf16x8*>(Wp) + (size_t)(wave * NTW) * 64 + lane;
+#pragma unroll
+    for (int s = 0; s < S; s++) {
+        bf16x8 a;
+#pragma unroll
+        for (int j = 0; j < 8; j++) a[j] = (__bf16)(row16 == 0 ? x[s * 32 + 8 * kq + j] : 0.0f);
+#pragma unroll
+        for (int i = 0; i < NTW; i++) {
+            bf16x8 b = Wv[((size_t)s * NT_TOTAL + i) * 64];
+            acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[i], 0, 0, 0);
+        }
+    }
+}
+
+// Accumulator layout helpers.  acc[mt][i][r] is pixel row = mt*16 + (lane>>4)*4 + r and output
+// channel = wave*(16*NTW) + (lane&15)*NTW + i  (the host packs B columns in that order so that a
+// lane owns NTW ADJACENT channels: per-channel parameters load as one vector, activations store
+// as one 8-byte LDS write).
+template <int NTW>
+__device__ inline int chan0(int wave, int lane) { return wave * (16 * NTW) + (lane & 15) * NTW; }
+
+// bias add + LayerNorm over `count` channels (eps 1e-6, timm LayerNorm2d) + optional ReLU, in place.
+// s_stat: LDS [64 rows][4 waves][2].
+template <int NTW>
+__device__ inline void bias_layernorm(f32x4 (&acc)[4][NTW], const float* __restrict__ bias, const float* __restrict__ gamma,
+                                      const float* __restrict__ beta, int count, bool relu, int wave, int lane, float* s_stat) {
+    const int c0 = chan0<NTW>(wave, lane);
+    float bv[NTW], gv[NTW], ev[NTW];
+#pragma unroll
+    for (int i = 0; i < NTW; i++) {
+        bv[i] = bias[c0 + i];
+        gv[i] = gamma[c0 + i];
+        ev[i] = beta[c0 + i];
+    }
+    float sum[4][4], sq[4][4];
+#pragma unroll
+    for (int mt = 0; mt < 4; mt++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            float s = 0.f, q = 0.f;
+#pragma unroll
+            for (int i = 0; i < NTW; i++) {
+                float v = acc[mt][i][r] + bv[i];
+                acc[mt][i][r] = v;
+                s += v;
+                q += v * v;
+            }
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) {
+                s += __shfl_xor(s, o, 64);
+                q += __shfl_xor(q, o, 64);
+            }
+            sum[mt][r] = s;
+            sq[mt][r] = q;
+        }
+    __syncthreads();  // previous users of s_stat are done
+    if ((lane & 15) == 0) {
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                int row = mt * 16 + (lane >> 4) * 4 + r;
+                reinterpret_cast<float2*>(s_stat)[row * 4 + wave] = make_float2(sum[mt][r], sq[mt][r]);
+            }
+    }
+    __syncthreads();
+    const float inv = 1.0f / (float)count;
+#pragma unroll
+    for (int mt = 0; mt < 4; mt++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            int row = mt * 16 + (lane >> 4) * 4 + r;
+            const float4* st = reinterpret_cast<const float4*>(s_stat) + row * 2;
+            float4 a = st[0], b = st[1];
+            float s = (a.x + a.z) + (b.x + b.z);
+            float q = (a.y + a.w) + (b.y + b.w);
+            float mean = s * inv;
+            float var = q * inv - mean * mean;
+            var = var < 0.f ? 0.f : var;
+            float rstd = 1.0f / sqrtf(var + 1e-6f);
+#pragma unroll
+            for (int i = 0; i < NTW; i++) {
+                float y = (acc[mt][i][r] - mean) * rstd * gv[i] + ev[i];
+                acc[mt][i][r] = (relu && y < 0.f) ? 0.f : y;
+            }
+        }
+}
+
+// store the accumulator tile as bf16 into an LDS image (pixel stride CP elements)
+template <int NTW, bool HALO>
+__device__ inline void store_image(const f32x4 (&acc)[4][NTW], bf16_t* X, int CP, int wave, int lane) {
+    const int c0 = chan0<NTW>(wave, lane);
+#pragma unroll
+    for (int mt = 0; mt < 4; mt++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            int p = mt * 16 + (lane >> 4) * 4 + r;
+            bf16_t* dst = X + (HALO ? hidx(p) : p) * CP + c0;
+            if (NTW == 4) {
+                uint2 v;
+                v.x = (uint32_t)f2bf(acc[mt][0][r]) | ((uint32_t)f2bf(acc[mt][1][r]) << 16);
+                v.y = (uint32_t)f2bf(acc[mt][2][r]) | ((uint32_t)f2bf(acc[mt][3][r]) << 16);
+                *reinterpret_cast<uint2*>(dst) = v;
+            } else {
+                uint32_t v = (uint32_t)f2bf(acc[mt][0][r]) | ((uint32_t)f2bf(acc[mt][1][r]) << 16);
+                *reinterpret_cast<uint32_t*>(dst) = v;
+            }
+        }
+}
+
+
+template <int C>
+__global__ __launch_bounds__(256, 1) void k_tower(TowerArgs A) {
+    constexpr int NTW = C / 64;        // column tiles per wave in the trunk (4 or 2)
+    constexpr int NT = C / 16;
+    constexpr int CP = C + 8;          // image pixel stride (elements): +16 B skews LDS banks
+    constexpr int HP = HEAD + 8;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    bf16_t* Xa = reinterpret_cast<bf16_t*>(smem);                           // [100][CP]
+    bf16_t* Xh = reinterpret_cast<bf16_t*>(smem + 100 * CP * 2);            // [64][HP]
+    float* s_stat = reinterpret_cast<float*>(smem + 100 * CP * 2 + 64 * HP * 2);  // [64][4][2]
+    float* s_vec = s_stat + 512;                                            // pooled[256] | hidden[128] | scale[256]
+    float* s_red = s_vec + 640;                                             // [8]
+    float* s_z = reinterpret_cast<float*>(smem);                            // policy logits [4672], aliases Xa (after the trunk)
+    static_assert(4672 * 4 <= 100 * CP * 2 + 64 * HP * 2, "policy logits must fit in the image area");
+
+    const int pos = blockIdx.x;
+    if (pos >= A.n_pos) return;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const NetDev& net = A.net;
+
+    // ---- zero the image (halo stays zero for the whole kernel), then load the 112 input planes
+    {
+        uint4* z = reinterpret_cast<uint4*>(Xa);
+        for (int i = tid; i < 100 * CP * 2 / 16; i += 256) z[i] = make_uint4(0, 0, 0, 0);
+    }
+    __syncthreads();
+    {
+        const int p = tid >> 2, q = tid & 3;
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(A.boards + (size_t)pos * 7168 + p * 112 + q * 28);
+        bf16_t* dst = Xa + hidx(p) * CP + q * 28;
+#pragma unroll
+        for (int k = 0; k < 7; k++) {
+            uint32_t w = src[k];
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                int8_t v = (int8_t)((w >> (8 * b)) & 0xff);
+                dst[k * 4 + b] = f2bf((float)v);
+            }
+        }
+    }
+    __syncthreads();
+
+    f32x4 acc[4][NTW], res[4][NTW];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++)
+#pragma unroll
+            for (int i = 0; i < NTW; i++) acc[mt][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+
+    // ---- conv_block (py/module.py:120-126): conv3x3 112->C (K padded to 128/tap), LN, ReLU
+    zero_acc();
+    conv_mma<128, 9, NTW, NT, true>(Xa, CP, net.wb + net.o_stem, wave, lane, acc);
+    {
+        const float* f = net.wf + net.f_stem;
+        bias_layernorm<NTW>(acc, f, f + C, f + 2 * C, C, true, wave, lane, s_stat);
+    }
+#pragma unroll
+    for (int mt = 0; mt < 4; mt++)
+#pragma unroll
+        for (int i = 0; i < NTW; i++) res[mt][i] = acc[mt][i];
+    __syncthreads();  // all waves finished reading the input image
+    store_image<NTW, true>(acc, Xa, CP, wave, lane);
+    __syncthreads();
+    auto dump = [&](int stage) {
+        if (A.dbg && A.dbg_stage == stage) {
+            const int c0 = chan0<NTW>(wave, lane);
+#pragma unroll
+            for (int mt = 0; mt < 4; mt++)
+#pragma unroll
+                for (int r = 0; r < 4; r++)
+#pragma unroll
+                    for (int i = 0; i < NTW; i++)
+                        A.dbg[((size_t)pos * 64 + mt * 16 + (lane >> 4) * 4 + r) * C + c0 + i] = res[mt][i][r];
+        }
+    };
+    dump(0);
+
+    // ---- residual tower (ResBlockSE.forward, py/module.py:38-46)
+#pragma unroll 1
+    for (int b = 0; b < net.n_blocks; b++) {
+        const bf16_t* wb = net.wb + net.o_blocks + (size_t)b * net.blk_stride_b;
+        const float* wf = net.wf + net.f_blocks + (size_t)b * net.blk_stride_f;
+        // conv1 -> LN -> ReLU
+        zero_acc();
+        conv_mma<C, 9, NTW, NT, true>(Xa, CP, wb, wave, lane, acc);
+        bias_layernorm<NTW>(acc, wf, wf + C, wf + 2 * C, C, true, wave, lane, s_stat);
+        __syncthreads();
+        store_image<NTW, true>(acc, Xa, CP, wave, lane);
+        __syncthreads();
+        // conv2 -> LN
+        zero_acc();
+        conv_mma<C, 9, NTW, NT, true>(Xa, CP, wb + (size_t)9 * C * C, wave, lane, acc);
+        bias_layernorm<NTW>(acc, wf + 3 * C, wf + 4 * C, wf + 5 * C, C, false, wave, lane, s_stat);
+        // squeeze-excitation: global average pool over the 64 pixels
+        {
+            float cs[NTW];
+#pragma unroll
+            for (int i = 0; i < NTW; i++) {
+                float s = 0.f;
+#pragma unroll
+                for (int mt = 0; mt < 4; mt++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) s += acc[mt][i][r];
+                s += __shfl_xor(s, 16, 64);
+                s += __shfl_xor(s, 32, 64);
+                cs[i] = s * (1.0f / 64.0f);
+            }
+            if (lane < 16) {
+                const int c0 = chan0<NTW>(wave, lane);
+#pragma unroll
+                for (int i = 0; i < NTW; i++) s_vec[c0 + i] = cs[i];
+            }
+        }
+        __syncthreads();
+        {
+            // fc1: C -> C/2, ReLU   (columns split over the 4 waves: C/2/16/4 tiles each)
+            constexpr int NT1 = C / 32, NTW1 = NT1 / 4;
+            f32x4 h[NTW1];
+#pragma unroll
+            for (int i = 0; i < NTW1; i++) h[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            vec_mma<C, NTW1, NT1>(s_vec, wb + (size_t)18 * C * C, wave, lane, h);
+            const float* b1 = wf + 6 * C;
+            if (lane < 16) {
+                const int j0 = chan0<NTW1>(wave, lane);
+#pragma unroll
+                for (int i = 0; i < NTW1; i++) {
+                    float v = h[i][0] + b1[j0 + i];
+                    s_vec[256 + j0 + i] = v > 0.f ? v : 0.f;
+                }
+            }
+        }
+        __syncthreads();
+        {
+            // fc2: C/2 -> C, sigmoid
+            f32x4 sc[NTW];
+#pragma unroll
+            for (int i = 0; i < NTW; i++) sc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            vec_mma<C / 2, NTW, NT>(s_vec + 256, wb + (size_t)18 * C * C + (size_t)C * (C / 2), wave, lane, sc);
+            const float* b2 = wf + 6 * C + C / 2;
+            if (lane < 16) {
+                const int c0 = chan0<NTW>(wave, lane);
+#pragma unroll
+                for (int i = 0; i < NTW; i++) {
+                    float v = sc[i][0] + b2[c0 + i];
+                    s_vec[384 + c0 + i] = 1.0f / (1.0f + __expf(-v));
+                }
+            }
+        }
+        __syncthreads();
+        {
+            const int c0 = chan0<NTW>(wave, lane);
+            float scl[NTW];
+#pragma unroll
+            for (int i = 0; i < NTW; i++) scl[i] = s_vec[384 + c0 + i];
+#pragma unroll
+            for (int mt = 0; mt < 4; mt++)
+#pragma unroll
+                for (int i = 0; i < NTW; i++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        float y = acc[mt][i][r] * scl[i] + res[mt][i][r];
+                        y = y > 0.f ? y : 0.f;
+                        res[mt][i][r] = y;
+                        acc[mt][i][r] = y;
+                    }
+        }
+        store_image<NTW, true>(acc, Xa, CP, wave, lane);  // conv2 finished reading Xa before the SE barriers
+        __syncthreads();
+        dump(b + 1);
+    }
+    dump(1000);
+
+    // ---- value head conv (py/module.py:89-94): conv1x1 C->256, LN, ReLU -> bf16 features in HBM
+    {
+        f32x4 hv[4][4];
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) hv[mt][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        conv_mma<C, 1, 4, 16, true>(Xa + 0, CP, net.wb + net.o_vconv, wave, lane, hv);
+        const float* f = net.wf + net.f_vhead;
+        bias_layernorm<4>(hv, f, f + HEAD, f + 2 * HEAD, HEAD, true, wave, lane, s_stat);
+        const int c0 = chan0<4>(wave, lane);
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                int p = mt * 16 + (lane >> 4) * 4 + r;
+                uint2 v;
+                v.x = (uint32_t)f2bf(hv[mt][0][r]) | ((uint32_t)f2bf(hv[mt][1][r]) << 16);
+                v.y = (uint32_t)f2bf(hv[mt][2][r]) | ((uint32_t)f2bf(hv[mt][3][r]) << 16);
+                *reinterpret_cast<uint2*>(A.hval + ((size_t)pos * 64 + p) * HEAD + c0) = v;
+            }
+    }
+    // ---- policy head (py/module.py:70-76): conv1x1 C->256, LN, conv1x1 256->73, LN (no ReLU between)
+    {
+        f32x4 hp[4][4];
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) hp[mt][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        conv_mma<C, 1, 4, 16, true>(Xa, CP, net.wb + net.o_pconv1, wave, lane, hp);
+        const float* f = net.wf + net.f_phead1;
+        bias_layernorm<4>(hp, f, f + HEAD, f + 2 * HEAD, HEAD, false, wave, lane, s_stat);
+        store_image<4, false>(hp, Xh, HP, wave, lane);
+    }
+    __syncthreads();
+    {
+        f32x4 z[4][2];
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++)
+#pragma unroll
+            for (int i = 0; i < 2; i++) z[mt][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        conv_mma<HEAD, 1, 2, 8, false>(Xh, HP, net.wb + net.o_pconv2, wave, lane, z);
+        const float* f = net.wf + net.f_phead2;
+        // padded channels (>=73) have zero weights, bias, gamma, beta: they add 0 to both LN sums
+        bias_layernorm<2>(z, f, f + POL_PAD, f + 2 * POL_PAD, 73, false, wave, lane, s_stat);
+        __syncthreads();  // everyone is done with Xa/Xh: the logits may overwrite the image area
+        const int c0 = chan0<2>(wave, lane);
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++)
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+#pragma unroll
+                for (int i = 0; i < 2; i++) {
+                    int ch = c0 + i, p = mt * 16 + (lane >> 4) * 4 + r;
+                    if (ch < 73) s_z[ch * 64 + p] = z[mt][i][r];  // Flatten is channel-major (module.py:75)
+                }
+    }
+    __syncthreads();
+    // ---- log_softmax over 4672 (module.py:80), then the legal-move gather of torch.rs:148-175
+    float mx = -3.0e38f;
+    for (int i = tid; i < 4672; i += 256) mx = fmaxf(mx, s_z[i]);
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    if (lane == 0) s_red[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+    float se = 0.f;
+    for (int i = tid; i < 4672; i += 256) se += __expf(s_z[i] - mx);
+    for (int o = 32; o > 0; o >>= 1) se += __shfl_xor(se, o, 64);
+    if (lane == 0) s_red[4 + wave] = se;
+    __syncthreads();
+    se = (s_red[4] + s_red[5]) + (s_red[6] + s_red[7]);
+    const float lse = mx + __logf(se);
+    if (A.logp) {
+        float* lp = A.logp + (size_t)pos * 4672;
+        for (int i = tid; i < 4672; i += 256) lp[i] = s_z[i] - lse;
+    }
+    if (A.prior) {
+        const int n = A.n_legal[pos];
+        const uint16_t* li = A.legal_idx + (size_t)pos * 224;
+        float e = 0.f;
+        if (tid < n) e = __expf(s_z[li[tid]] - lse);  // n <= 218 < 256 threads
+        float s = e;
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        __syncthreads();
+        if (lane == 0) s_red[wave] = s;
+        __syncthreads();
+        s = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]) + 1e-5f;  // post_process_distr (chess.rs:891)
+        if (tid < n) A.prior[(size_t)pos * 224 + tid] = e / s;
+    }
+}
+
+// --------------------------------------------------------------------------------------------
+// value_head.ffn.0 (Linear 16391->128) over the whole batch: out[b][j] = sum_k hval[b][k] W[k][j].
+// grid = (ceil(n/64), KSPLIT); block 256 = 4 waves, wave w owns column tiles 2w, 2w+1.
+// Partial sums go to vpart[ksplit][b][128]; k_value_finish reduces them in fixed order.
+__global__ __launch_bounds__(256) void k_value_fc1(Fc1Args A) {
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int mb = blockIdx.x, ks = blockIdx.y;
+    const int kchunk = FC1_K / A.ksplit;  // multiple of 32
+    const int steps = kchunk / 32;
+    const int row16 = lane & 15, kq = lane >> 4;
+    const bf16_t* arow[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; mt++) {
+        int row = mb * 64 + mt * 16 + row16;
+        if (row >= A.n_pos) row = A.n_pos - 1;
+        arow[mt] = A.hval + (size_t)row * FC1_K + (size_t)ks * kchunk + 8 * kq;
+    }
+    const bf16x8* Wv = reinterpret_cast<const bf16x8*>(A.net.wb + A.net.o_fc1) + ((size_t)(ks * steps) * 8 + wave * 2) * 64 + lane;
+    f32x4 acc[4][2];
+#pragma unroll
+    for (int mt = 0; mt < 4; mt++)
+#pragma unroll
+        for (int i = 0; i < 2; i++) acc[mt][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < steps; s++) {
+        bf16x8 b0 = Wv[((size_t)s * 8 + 0) * 64], b1 = Wv[((size_t)s * 8 + 1) * 64];
+        bf16x8 a[4];
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++) a[mt] = *reinterpret_cast<const bf16x8*>(arow[mt] + s * 32);
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++) {
+            acc[mt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt], b0, acc[mt][0], 0, 0, 0);
+            acc[mt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt], b1, acc[mt][1], 0, 0, 0);
+        }
+    }
+    const int c0 = chan0<2>(wave, lane);
+#pragma unroll
+    for (int mt = 0; mt < 4; mt++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            int row = mb * 64 + mt * 16 + (lane >> 4) * 4 + r;
+            if (row < A.n_pos)
+                *reinterpret_cast<float2*>(A.vpart + ((size_t)ks * A.n_pos + row) * FC1_N + c0) =
+                    make_float2(acc[mt][0][r], acc[mt][1][r]);
+        }
+}
+
+// value head tail (py/module.py:95-106,147-149): + meta columns + bias, ReLU, Linear 128->1, tanh,
+// times (2*turn-1).  One wave per position.
+__global__ __launch_bounds__(64) void k_value_finish(VfinArgs A) {
+    const int pos = blockIdx.x, lane = threadIdx.x;
+    if (pos >= A.n_pos) return;
+    const float* wf = A.net.wf;
+    float m[7];
+#pragma unroll
+    for (int k = 0; k < 7; k++) m[k] = bf2f(f2bf((float)A.meta[(size_t)pos * A.meta_stride + k]));  // meta is fed as bf16 (torch.rs:120-123)
+    float part = 0.f;
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        int j = lane + 64 * h;
+        float s = wf[A.net.f_fc1b + j];
+        for (int ks = 0; ks < A.ksplit; ks++) s += A.vpart[((size_t)ks * A.n_pos + pos) * FC1_N + j];
+#pragma unroll
+        for (int k = 0; k < 7; k++) s += m[k] * wf[A.net.f_fc1m + k * FC1_N + j];
+        s = s > 0.f ? s : 0.f;
+        part += s * wf[A.net.f_fc2w + j];
+    }
+    for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+    if (lane == 0) {
+        float v = tanhf(part + wf[A.net.f_fc2b]);
+        A.value[pos] = v * (float)(A.meta[(size_t)pos * A.meta_stride] * 2 - 1);
+    }
+}
+
+}  // namespace scnn

@@ -109,14 +109,16 @@ void sct_pop(sct_state* s) {
     s->moves.pop_back();
 }
 int sct_legal_moves(const sct_state* s, uint16_t* out, int* in_check) {
-    MoveList l;
+    move_t buf[MAX_MOVES];
+    MoveList l{buf, 0};
     bool chk = gen_legal(s->hist.back(), l);
     if (in_check) *in_check = chk;
     memcpy(out, l.m, sizeof(move_t) * (size_t)l.n);
     return l.n;
 }
 static uint64_t perft(const Position& p, int depth) {
-    MoveList l;
+    move_t buf[MAX_MOVES];
+    MoveList l{buf, 0};
     gen_legal(p, l);
     if (depth == 1) return (uint64_t)l.n;
     uint64_t t = 0;
@@ -140,7 +142,8 @@ uint64_t sct_pos_hash(const sct_state* s) { return synth_pos_hash(s->hist.back()
 uint64_t sct_key(const sct_state* s) { return s->hist.back().key; }
 uint64_t sct_rng(uint64_t a, uint64_t b, uint64_t c, uint64_t d, uint64_t e) { return sc_rng(a, b, c, d, e); }
 void sct_synth_eval(const sct_state* s, float* priors, float* value) {
-    MoveList l;
+    move_t buf[MAX_MOVES];
+    MoveList l{buf, 0};
     gen_legal(s->hist.back(), l);
     uint64_t h = synth_pos_hash(s->hist.back());
     uint64_t sum = 0;

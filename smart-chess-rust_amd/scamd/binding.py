@@ -1,0 +1,370 @@
+"""ctypes binding of include/sc_engine.h (libsc_engine.so)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libsc_engine.so")
+
+MAX_MOVES = 224
+TERMINATION = {0: None, 1: "Checkmate", 2: "Stalemate", 3: "InsufficientMaterial", 4: "SeventyfiveMoves",
+               5: "FivefoldRepetition", 6: "FiftyMoves", 7: "ThreefoldRepetition"}
+_WINNER = {1: "White", 0: "Black", -1: None}
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+class NetConfig(C.Structure):
+    _fields_ = [("n_res_blocks", C.c_int32), ("channels", C.c_int32), ("seed", C.c_uint64)]
+
+
+class SelfplayConfig(C.Structure):
+    _fields_ = [("n_slots", C.c_int32), ("n_games", C.c_int32), ("rollout_num", C.c_int32), ("num_steps", C.c_int32),
+                ("cpuct", C.c_float), ("temperature", C.c_float), ("temperature_switch", C.c_int32),
+                ("epsilon", C.c_float), ("with_noise", C.c_int32), ("outcome_gate", C.c_int32),
+                ("evaluator", C.c_int32), ("external_noise", C.c_int32), ("seed", C.c_uint64),
+                ("first_game_id", C.c_uint64)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("sims_done", C.c_int64), ("nn_evals", C.c_int64), ("games_finished", C.c_int32),
+                ("games_active", C.c_int32), ("error_flags", C.c_int32), ("plies_done", C.c_int32)]
+
+
+class TraceInfo(C.Structure):
+    _fields_ = [("n_steps", C.c_int32), ("n_children_total", C.c_int32), ("has_outcome", C.c_int32),
+                ("termination", C.c_int32), ("winner", C.c_int32), ("game_id", C.c_uint64)]
+
+
+# every symbol include/sc_engine.h declares: name -> (restype, argtypes)
+_vp, _i, _i64, _u16p, _f = C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_float
+ABI = {
+    "sc_last_error": (C.c_char_p, []),
+    "sc_device_count": (_i, []),
+    "sc_engine_create": (_i, [C.POINTER(NetConfig), C.c_char_p, _i, C.POINTER(_vp)]),
+    "sc_engine_destroy": (None, [_vp]),
+    "sc_engine_max_batch": (_i, [_vp]),
+    "sc_forward_batch": (_i, [_vp, _i, _vp, _vp, _vp, _vp]),
+    "sc_predict_batch": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "sc_predict_batch_device": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "sc_engine_synchronize": (_i, [_vp]),
+    "sc_forward_debug": (_i, [_vp, _i, _vp, _vp, _i, _vp]),
+    "sc_encode_positions": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "sc_selfplay_create": (_i, [_vp, _i, C.POINTER(SelfplayConfig), C.POINTER(_vp)]),
+    "sc_selfplay_destroy": (None, [_vp]),
+    "sc_selfplay_enqueue_sims": (_i, [_vp, _i]),
+    "sc_selfplay_synchronize": (_i, [_vp]),
+    "sc_selfplay_run": (_i, [_vp, _i64]),
+    "sc_selfplay_get_stats": (_i, [_vp, C.POINTER(Stats)]),
+    "sc_selfplay_enable_timing": (_i, [_vp, _i]),
+    "sc_selfplay_timing": (_i, [_vp, _i, C.POINTER(_f), C.POINTER(_f), C.POINTER(_i64)]),
+    "sc_selfplay_get_trace": (_i, [_vp, _i, C.POINTER(TraceInfo), _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "sc_selfplay_write_trace_json": (_i, [_vp, _i, C.c_char_p]),
+    "sc_selfplay_get_tree": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "sc_selfplay_get_slot": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "sc_selfplay_set_noise": (_i, [_vp, _i, _vp, _i]),
+    "sc_selfplay_get_noise": (_i, [_vp, _i, _vp, _i]),
+    "sc_selfplay_set_position": (_i, [_vp, _i, _vp, _i]),
+    "sc_trace_write_json": (_i, [C.c_char_p, C.POINTER(TraceInfo), _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "sc_move_uci": (_i, [C.c_uint16, C.c_char_p]),
+}
+
+_lib = None
+
+
+def lib_path():
+    return _LIB_PATH
+
+
+def lib():
+    """Loads libsc_engine.so; raises EngineError (never falls back) when it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise EngineError(f"{_LIB_PATH} is missing: build it with `python smart-chess-rust_amd/build.py` "
+                          "(there is no CPU fallback)")
+    try:
+        L = C.CDLL(_LIB_PATH)
+    except OSError as e:  # pragma: no cover
+        raise EngineError(f"cannot load {_LIB_PATH}: {e}") from e
+    for name, (res, args) in ABI.items():
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+def _check(rc):
+    if rc != 0:
+        raise EngineError(f"libsc_engine error {rc}: {lib().sc_last_error().decode()}")
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def move_uci(m):
+    buf = C.create_string_buffer(8)
+    lib().sc_move_uci(int(m), buf)
+    return buf.value.decode()
+
+
+def uci_move(s):
+    promo = {"n": 2, "b": 3, "r": 4, "q": 5}
+    f = (ord(s[1]) - 49) * 8 + ord(s[0]) - 97
+    t = (ord(s[3]) - 49) * 8 + ord(s[2]) - 97
+    return f | (t << 6) | ((promo[s[4]] if len(s) > 4 else 0) << 12)
+
+
+class Engine:
+    """The network backend (replaces ChessTS/ChessEP/ChessOnnx construction, src/main.rs:83-128)."""
+
+    def __init__(self, n_res_blocks=10, channels=256, seed=0, weights=None, device=0):
+        self.L = lib()
+        self.n_res_blocks, self.channels = n_res_blocks, channels
+        cfg = NetConfig(n_res_blocks, channels, seed)
+        h = C.c_void_p()
+        _check(self.L.sc_engine_create(C.byref(cfg), weights.encode() if weights else None, device, C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.sc_engine_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def forward(self, boards, meta, want_logp=True):
+        """ChessModule.forward: boards int8[n,8,8,112], meta int32[n,7] -> logp[n,4672], value[n]"""
+        boards = np.ascontiguousarray(boards, np.int8).reshape(-1, 8, 8, 112)
+        meta = np.ascontiguousarray(meta, np.int32).reshape(-1, 7)
+        n = boards.shape[0]
+        logp = np.zeros((n, 4672), np.float32) if want_logp else None
+        value = np.zeros(n, np.float32)
+        _check(self.L.sc_forward_batch(self.h, n, _p(boards), _p(meta), _p(logp), _p(value)))
+        return logp, value
+
+    def debug(self, boards, meta, stage):
+        boards = np.ascontiguousarray(boards, np.int8).reshape(-1, 8, 8, 112)
+        meta = np.ascontiguousarray(meta, np.int32).reshape(-1, 7)
+        n = boards.shape[0]
+        out = np.zeros((n, 64, self.channels), np.float32)
+        _check(self.L.sc_forward_debug(self.h, n, _p(boards), _p(meta), stage, _p(out)))
+        return out
+
+    def predict(self, boards, meta, legal_idx):
+        """Game::predict tail: legal_idx = list (per position) of action indices -> (list of priors, value[n])"""
+        boards = np.ascontiguousarray(boards, np.int8).reshape(-1, 8, 8, 112)
+        meta = np.ascontiguousarray(meta, np.int32).reshape(-1, 7)
+        n = boards.shape[0]
+        off = np.zeros(n + 1, np.uint32)
+        off[1:] = np.cumsum([len(x) for x in legal_idx])
+        flat = np.ascontiguousarray(np.concatenate([np.asarray(x, np.uint16) for x in legal_idx]) if off[-1] else
+                                    np.zeros(0, np.uint16), np.uint16)
+        pri = np.zeros(int(off[-1]), np.float32)
+        value = np.zeros(n, np.float32)
+        _check(self.L.sc_predict_batch(self.h, n, _p(boards), _p(meta), _p(flat), _p(off), _p(pri), _p(value)))
+        return [pri[off[i]:off[i + 1]] for i in range(n)], value
+
+
+def encode_positions(move_lists, device=0, engine=None):
+    """Rules + encoder on the GPU for positions given as move lists (uint16 moves or UCI strings)."""
+    L = lib()
+    n = len(move_lists)
+    ml = [[uci_move(m) if isinstance(m, str) else int(m) for m in g] for g in move_lists]
+    off = np.zeros(n + 1, np.uint32)
+    off[1:] = np.cumsum([len(g) for g in ml])
+    flat = np.asarray([m for g in ml for m in g], np.uint16)
+    if flat.size == 0:
+        flat = np.zeros(1, np.uint16)
+    boards = np.zeros((n, 8, 8, 112), np.int8)
+    meta = np.zeros((n, 7), np.int32)
+    lm = np.zeros((n, MAX_MOVES), np.uint16)
+    li = np.zeros((n, MAX_MOVES), np.uint16)
+    nl = np.zeros(n, np.int32)
+    oc = np.zeros((n, 4), np.int32)
+    _check(L.sc_encode_positions(engine.h if engine else None, device, n, _p(flat), _p(off), _p(boards), _p(meta), _p(lm),
+                                 _p(li), _p(nl), _p(oc)))
+    return dict(boards=boards, meta=meta, legal_moves=[lm[i, :nl[i]].copy() for i in range(n)],
+                legal_idx=[li[i, :nl[i]].copy() for i in range(n)], n_legal=nl, termination=oc[:, 0], winner=oc[:, 1],
+                is_check=oc[:, 2], status=oc[:, 3])
+
+
+class ChessHip:
+    """Mirror of `impl Game<BoardState> for ChessTS` (src/backends/torch.rs:34-53) over the GPU engine.
+
+    A node/state pair of the reference is represented by the list of moves played from the start
+    position (that is what `_encode` reconstructs from the tree's parent chain and the board's
+    move stack, src/chess.rs:845-867).
+    """
+
+    def __init__(self, engine):
+        self.engine = engine
+
+    def predict(self, moves, argmax=False):
+        """-> (steps, priors, value): steps = legal moves (uint16) in python-chess order; empty at game end,
+        with value = +1 White won / -1 Black won / 0 (torch.rs:98-106)."""
+        enc = encode_positions([moves], engine=self.engine)
+        if enc["status"][0] < 0:
+            raise EngineError(f"illegal move at index {-enc['status'][0] - 1}")
+        if enc["n_legal"][0] == 0:
+            w = enc["winner"][0]
+            return [], np.zeros(0, np.float32), (1.0 if w == 1 else -1.0 if w == 0 else 0.0)
+        pri, val = self.engine.predict(enc["boards"], enc["meta"], [enc["legal_idx"][0]])
+        p = pri[0]
+        if argmax:  # post_process_distr argmax branch (src/chess.rs:880-889)
+            o = np.zeros_like(p)
+            o[int(np.argmax(p))] = 1.0
+            p = o
+        return list(enc["legal_moves"][0]), p, float(val[0])
+
+    @staticmethod
+    def reverse_q(moves):
+        """node.step.1 == Black (torch.rs:49-52): Black is to move after an odd number of plies"""
+        return len(moves) % 2 == 1
+
+
+class SelfPlay:
+    """Batched `selfplay` (src/main.rs): same option names as the reference CLI (main.rs:25-60)."""
+
+    def __init__(self, engine=None, n_slots=256, n_games=None, rollout_num=180, num_steps=150, cpuct=2.5,
+                 temperature=0.0, temperature_switch=4, epsilon=0.15, with_noise=True, outcome_gate=100,
+                 evaluator="net", external_noise=False, seed=0, first_game_id=0, device=0):
+        self.L = lib()
+        self.engine = engine
+        cfg = SelfplayConfig(n_slots, n_games if n_games is not None else n_slots, rollout_num, num_steps, cpuct,
+                             temperature, temperature_switch, epsilon, int(with_noise), outcome_gate,
+                             0 if evaluator == "net" else 1, int(external_noise), seed, first_game_id)
+        self.cfg = cfg
+        h = C.c_void_p()
+        _check(self.L.sc_selfplay_create(engine.h if engine else None, device, C.byref(cfg), C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.sc_selfplay_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def enqueue(self, n_sims):
+        _check(self.L.sc_selfplay_enqueue_sims(self.h, n_sims))
+
+    def sync(self):
+        _check(self.L.sc_selfplay_synchronize(self.h))
+
+    def run(self, max_sim_steps=0):
+        _check(self.L.sc_selfplay_run(self.h, max_sim_steps))
+
+    def stats(self):
+        s = Stats()
+        _check(self.L.sc_selfplay_get_stats(self.h, C.byref(s)))
+        return {k: getattr(s, k) for k, _ in Stats._fields_}
+
+    def enable_timing(self, stride=1):
+        _check(self.L.sc_selfplay_enable_timing(self.h, stride))
+
+    def timing(self, reset=True):
+        a, b, n = C.c_float(0), C.c_float(0), C.c_int64(0)
+        _check(self.L.sc_selfplay_timing(self.h, int(reset), C.byref(a), C.byref(b), C.byref(n)))
+        return dict(ms_total=a.value, ms_tower_sum=b.value, tower_launches=n.value)
+
+    def trace(self, game):
+        """-> dict in the reference's trace-file shape (src/trace.rs:5-9) or None if unfinished"""
+        info = TraceInfo()
+        rc = self.L.sc_selfplay_get_trace(self.h, game, C.byref(info), None, None, None, None, None, None, None)
+        if rc == 1:
+            return None
+        _check(rc)
+        ns, nc = info.n_steps, info.n_children_total
+        sm, sq = np.zeros(ns + 1, np.uint16), np.zeros(ns + 1, np.float32)
+        co = np.zeros(ns + 2, np.int32)
+        cm, cn = np.zeros(nc + 1, np.uint16), np.zeros(nc + 1, np.int32)
+        cq, cu = np.zeros(nc + 1, np.float32), np.zeros(nc + 1, np.float32)
+        _check(self.L.sc_selfplay_get_trace(self.h, game, C.byref(info), _p(sm), _p(sq), _p(co), _p(cm), _p(cn), _p(cq),
+                                            _p(cu)))
+        steps = []
+        for i in range(ns):
+            ch = [(move_uci(cm[j]), int(cn[j]), float(cq[j]), float(cu[j])) for j in range(co[i], co[i + 1])]
+            steps.append((move_uci(sm[i]), float(sq[i]), ch))
+        outcome = None
+        if info.has_outcome:
+            outcome = {"termination": TERMINATION[info.termination], "winner": _WINNER[info.winner]}
+        return {"steps": steps, "outcome": outcome, "game_id": int(info.game_id)}
+
+    def write_trace(self, game, path):
+        _check(self.L.sc_selfplay_write_trace_json(self.h, game, path.encode()))
+
+    def tree(self, slot, cap=1 << 20):
+        n = self.L.sc_selfplay_get_tree(self.h, slot, 0, None, None, None, None, None, None, None)
+        if n < 0:
+            _check(n)
+        n = min(n, cap)
+        out = dict(n=np.zeros(n, np.int32), q=np.zeros(n, np.float32), uct=np.zeros(n, np.float32),
+                   prior=np.zeros(n, np.float32), move=np.zeros(n, np.uint16), first_child=np.zeros(n, np.int32),
+                   n_child=np.zeros(n, np.int32))
+        r = self.L.sc_selfplay_get_tree(self.h, slot, n, _p(out["n"]), _p(out["q"]), _p(out["uct"]), _p(out["prior"]),
+                                        _p(out["move"]), _p(out["first_child"]), _p(out["n_child"]))
+        if r < 0:
+            _check(r)
+        return out
+
+    def slot(self, slot):
+        ply, sim, st, plen = C.c_int32(0), C.c_int32(0), C.c_int32(0), C.c_int32(0)
+        gid = C.c_uint64(0)
+        path = np.zeros(1024, np.int32)
+        _check(self.L.sc_selfplay_get_slot(self.h, slot, C.byref(ply), C.byref(sim), C.byref(st), C.byref(gid), _p(path),
+                                           C.byref(plen)))
+        return dict(ply=ply.value, sim=sim.value, status=st.value, game_id=gid.value, path=path[:plen.value].copy())
+
+    def set_noise(self, slot, noise):
+        noise = np.ascontiguousarray(noise, np.float32)
+        _check(self.L.sc_selfplay_set_noise(self.h, slot, _p(noise), noise.size))
+
+    def get_noise(self, slot, n):
+        out = np.zeros(MAX_MOVES, np.float32)
+        _check(self.L.sc_selfplay_get_noise(self.h, slot, _p(out), MAX_MOVES))
+        return out[:n]
+
+    def set_position(self, slot, moves):
+        mv = np.asarray([uci_move(m) if isinstance(m, str) else int(m) for m in moves], np.uint16)
+        if mv.size == 0:
+            mv = np.zeros(1, np.uint16)
+        _check(self.L.sc_selfplay_set_position(self.h, slot, _p(mv), len(moves)))
+
+
+def write_trace_json(path, trace):
+    """sc_trace_write_json on a trace dict (no GPU needed)."""
+    steps = trace["steps"]
+    ns = len(steps)
+    info = TraceInfo()
+    info.n_steps = ns
+    oc = trace.get("outcome")
+    info.has_outcome = int(oc is not None)
+    inv_t = {v: k for k, v in TERMINATION.items()}
+    info.termination = inv_t[oc["termination"]] if oc else 0
+    info.winner = {"White": 1, "Black": 0, None: -1}[oc["winner"]] if oc else -1
+    sm = np.asarray([uci_move(s[0]) for s in steps] + [0], np.uint16)
+    sq = np.asarray([s[1] for s in steps] + [0], np.float32)
+    co = np.zeros(ns + 2, np.int32)
+    co[1:ns + 1] = np.cumsum([len(s[2]) for s in steps])
+    ch = [c for s in steps for c in s[2]]
+    info.n_children_total = len(ch)
+    cm = np.asarray([uci_move(c[0]) for c in ch] + [0], np.uint16)
+    cn = np.asarray([c[1] for c in ch] + [0], np.int32)
+    cq = np.asarray([c[2] for c in ch] + [0], np.float32)
+    cu = np.asarray([c[3] for c in ch] + [0], np.float32)
+    _check(lib().sc_trace_write_json(path.encode(), C.byref(info), _p(sm), _p(sq), _p(co), _p(cm), _p(cn), _p(cq), _p(cu)))
