@@ -1,0 +1,265 @@
+#!/usr/bin/env python3
+"""bench.py -- MCTS simulations/sec of the self-play hot path on N MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one ply of self-play for every concurrent game on a GPU = `rollout` (180) simulation steps of
+the whole hot path (select -> encode -> network -> expand -> backup, mcts.rs:261-288) over `games` (256)
+boards, plus the per-ply move choice (mcts::step).  Workload (BASELINE.json configs[1]): 256 concurrent
+self-play games per GPU from the start position, rollout = 180, 10-block ResNet bf16, Dirichlet noise on,
+cpuct 2.5, temperature switch 4 (README.md:39 of the reference).  Everything is resident in HBM before the
+timed region; games shard across ranks with no collective on the data path (weak scaling).
+
+Prints ONE JSON line (rank 0) with `roofline` (dominant kernel = the network tower, priced against the
+dense bf16 MFMA peak) and, at N=1, `cpu_baseline` (the CPU oracle = port of the reference algorithm,
+timed on the host cores on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "smart-chess-rust_amd"))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0  # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md, chip-level parameters)
+HBM_PEAK_GBS = 8000.0
+
+
+def macs_per_position(n_blocks, C):
+    """MACs of one forward of one position (BASELINE.md section 2 / SURVEY.md section 8d)."""
+    H = 256
+    stem = 64 * 112 * 9 * C
+    block = 2 * 64 * C * 9 * C + 2 * C * (C // 2)
+    policy = 64 * C * H + 64 * H * 73
+    value = 64 * C * H + (64 * H + 7) * 128 + 128
+    return stem + n_blocks * block + policy + value
+
+
+def shard(total_games_per_rank, rank):
+    """game-id range of a rank: ids are globally unique so traces from different GPUs never collide"""
+    return rank * total_games_per_rank
+
+
+def cpu_baseline(n_blocks, C, budget_s, rollout):
+    """Reference algorithm on the host cores: the CPU oracle (oracle/, a port -- the Rust binary cannot be
+    built here) in reference-faithful mode (network re-evaluated at every node of every descent, batch 1,
+    fp32, src/mcts.rs:152), one game per core."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import oracle_py as orc
+
+    orc.build()
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = max(1, min(cores, 16))
+    net = orc.Net(n_blocks, C, seed=1)
+    ev = orc.eval_fn("orc_eval_net")
+
+    def worker(i, faithful, budget):
+        st = orc.State()
+        s = orc.Search(st)
+        t0 = time.time()
+        n = 0
+        while time.time() - t0 < budget and n < rollout:
+            s.sim(evaluator=ev, user=net.h, cpuct=2.5, epsilon=0.15, with_noise=True, faithful=faithful)
+            n += 1
+        return n, s.num_evals(), time.time() - t0
+
+    out = {}
+    for name, faithful, budget in (("faithful", True, budget_s * 0.7), ("cached", False, budget_s * 0.3)):
+        t0 = time.time()
+        with ThreadPoolExecutor(cores) as ex:
+            res = list(ex.map(lambda i: worker(i, faithful, budget), range(cores)))
+        wall = time.time() - t0
+        out[name] = (sum(r[0] for r in res) / wall, sum(r[1] for r in res), wall)
+    return {
+        "value": round(out["faithful"][0], 2),
+        "unit": "simulations/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": (f"{cores} games (one per core, 1 thread each), simulations of ply 0 from the start position for "
+                   f"{budget_s * 0.7:.0f} s, fp32 {n_blocks}x{C} net re-evaluated at every path node (reference-faithful, "
+                   f"{out['faithful'][1]} net calls); CPU oracle = restatement of the reference algorithm, not the Rust binary"),
+        "cached_prior_value": round(out["cached"][0], 2),
+    }
+
+
+def run_gpu(args, rank, world, local_rank):
+    import scamd
+
+    G, R = args.games, args.rollout
+    res = {}
+    for tag, C in (("main", args.channels),) + ((("alt", 256 if args.channels == 128 else 128),) if args.alt and world == 1 else ()):
+        eng = scamd.Engine(args.blocks, C, seed=1, device=local_rank)
+        sp = scamd.SelfPlay(eng, n_slots=G, n_games=10 ** 7, trace_capacity=4 * G, rollout_num=R, num_steps=150, cpuct=2.5,
+                            temperature=0.0, temperature_switch=4, epsilon=0.15, with_noise=True, seed=1234,
+                            first_game_id=shard(10 ** 7, rank), device=local_rank)
+        steps = args.steps if tag == "main" else max(2, args.steps // 4)
+        sp.enqueue(args.warmup * R)
+        sp.sync()
+        s0 = sp.stats()
+        sp.enable_timing(args.timing_stride)
+        sp.timing(reset=True)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            sp.enqueue(R)
+        sp.sync()
+        cuda_sync()
+        t1 = time.perf_counter()
+        barrier()
+        tm = sp.timing()
+        s1 = sp.stats()
+        res[tag] = dict(C=C, seconds=t1 - t0, steps=steps, sims=s1["sims_done"] - s0["sims_done"],
+                        nn_evals=s1["nn_evals"] - s0["nn_evals"], err=s1["error_flags"],
+                        tower_ms=tm["ms_tower_sum"] / max(tm["tower_launches"], 1), tower_launches=tm["tower_launches"],
+                        span_ms=tm["ms_total"])
+        sp.close()
+        eng.close()
+    return res
+
+
+_dist = None
+
+
+def barrier():
+    if _dist is not None:
+        _dist.barrier()
+
+
+def cuda_sync():
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+    except Exception:
+        pass
+
+
+def main():
+    global _dist
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--games", type=int, default=256, help="concurrent games per GPU")
+    ap.add_argument("--rollout", type=int, default=180)
+    ap.add_argument("--blocks", type=int, default=10)
+    ap.add_argument("--channels", type=int, default=128, help="trunk width: 128 = BASELINE configs[1]; 256 = reference module")
+    ap.add_argument("--no-alt", dest="alt", action="store_false", help="skip the short run of the other trunk width")
+    ap.add_argument("--timing-stride", type=int, default=1)
+    ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU work for cpu_baseline (0 = skip)")
+    ap.add_argument("--cpu-dry-run", action="store_true",
+                    help="HARNESS TEST ONLY (gloo, no GPU): exercises sharding/timing/aggregation with the oracle's "
+                         "synthetic self-play as stand-in workload; its numbers are meaningless")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    torch = None
+    try:
+        import torch  # plumbing only: rendezvous, barrier, max-over-ranks
+    except Exception:
+        if world > 1:
+            raise
+    if world > 1:
+        import torch.distributed as dist
+        backend = "gloo" if args.cpu_dry_run else "nccl"
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        _dist = dist
+
+    if args.cpu_dry_run:
+        from oracle import oracle_py as orc
+        barrier()
+        t0 = time.perf_counter()
+        sims = 0
+        for k in range(args.steps):
+            g = orc.selfplay_game(rollout_num=8, num_steps=2, seed=1234, game_id=shard(10 ** 7, rank) + k)
+            sims += g["n_sims"]
+        t1 = time.perf_counter()
+        barrier()
+        res = {"main": dict(C=args.channels, seconds=t1 - t0, steps=args.steps, sims=sims, nn_evals=0, err=0, tower_ms=0.0,
+                            tower_launches=0, span_ms=0.0)}
+    else:
+        res = run_gpu(args, rank, world, local_rank)
+
+    m = res["main"]
+    seconds, sims = m["seconds"], float(m["sims"])
+    if world > 1:
+        t = torch.tensor([seconds], dtype=torch.float64)
+        s = torch.tensor([sims], dtype=torch.float64)
+        if not args.cpu_dry_run:
+            t, s = t.cuda(), s.cuda()
+        _dist.all_reduce(t, op=_dist.ReduceOp.MAX)   # timing only -- no collective on the data path
+        _dist.all_reduce(s, op=_dist.ReduceOp.SUM)
+        seconds, sims = float(t.item()), float(s.item())
+    if rank == 0:
+        flop_pos = 2.0 * macs_per_position(args.blocks, m["C"])
+        out = {
+            "metric": "MCTS simulations/sec (whole node), self-play rollout=180",
+            "value": round(sims / seconds, 1),
+            "unit": "simulations/s",
+            "n_gpus": world,
+            "steps": m["steps"],
+            "warmup": args.warmup,
+            "ms_per_step": round(1e3 * seconds / m["steps"], 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "bf16",
+            "data": "synthetic" if not args.cpu_dry_run else "cpu-dry-run (oracle stand-in; harness test only)",
+            "config": {
+                "workload": (f"BASELINE configs[1]: {args.games} concurrent self-play games per GPU from the start position, "
+                             f"rollout={args.rollout}, {args.blocks}-block/{m['C']}-ch SE-ResNet bf16 (random-init), "
+                             "cpuct 2.5, Dirichlet(0.3) eps 0.15, temperature switch 4"),
+                "games_per_gpu": args.games, "rollout": args.rollout, "net": f"{args.blocks}x{m['C']}",
+                "step": "one ply = rollout simulation steps over all games", "parallelism": f"games sharded over {world} GPU(s), no collective",
+            },
+        }
+        if not args.cpu_dry_run:
+            tf = args.games * flop_pos / (m["tower_ms"] * 1e-3) / 1e12 if m["tower_ms"] > 0 else 0.0
+            out["roofline"] = {
+                "bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(tf / PEAK_BF16_TFLOPS, 4), "traffic": load_traffic(m["C"]),
+                "kernel": f"k_tower<{m['C']}>", "avg_launch_ms": round(m["tower_ms"], 4), "launches_timed": m["tower_launches"],
+                "flop_per_launch": args.games * flop_pos,
+                "end_to_end_frac": round(sims / seconds / world * flop_pos / (PEAK_BF16_TFLOPS * 1e12), 4),
+            }
+            out["nn_evals_per_sim"] = round(m["nn_evals"] / max(m["sims"], 1), 4)
+            out["error_flags"] = m["err"]
+            if "alt" in res:
+                a = res["alt"]
+                fa = 2.0 * macs_per_position(args.blocks, a["C"])
+                out["also"] = {"net": f"{args.blocks}x{a['C']}", "value": round(a["sims"] / a["seconds"], 1),
+                               "ms_per_step": round(1e3 * a["seconds"] / a["steps"], 3),
+                               "tower_avg_ms": round(a["tower_ms"], 4),
+                               "roofline_frac": round(args.games * fa / (a["tower_ms"] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4)
+                               if a["tower_ms"] > 0 else None}
+            if world == 1 and args.cpu_budget > 0:
+                out["cpu_baseline"] = cpu_baseline(args.blocks, m["C"], args.cpu_budget, args.rollout)
+        print(json.dumps(out), flush=True)
+    if _dist is not None:
+        _dist.barrier()
+        _dist.destroy_process_group()
+
+
+def load_traffic(C):
+    """HBM bytes per tower launch from the rocprofv3 PMC passes committed under profiles/ (null if not collected)"""
+    p = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        return json.load(open(p)).get(f"k_tower<{C}>")
+    except Exception:
+        return None
+
+
+if __name__ == "__main__":
+    main()

@@ -107,6 +107,9 @@ typedef struct {
     int32_t external_noise;     /* tests: root noise is taken from sc_selfplay_set_noise instead of the device RNG */
     uint64_t seed;
     uint64_t first_game_id;     /* global id of this handle's first game (sharding across GPUs/ranks) */
+    int32_t trace_capacity;     /* traces kept on the device: 0 = n_games (every trace retrievable); >0 = ring of that
+                                   many games (>= 2*n_slots), older traces are overwritten (throughput runs) */
+    int32_t reserved;
 } sc_selfplay_config;
 
 int sc_selfplay_create(sc_engine* engine_or_null, int device_id, const sc_selfplay_config* cfg, sc_selfplay** out);

@@ -378,7 +378,7 @@ int sc_selfplay_create(sc_engine* e, int device_id, const sc_selfplay_config* cf
     p.max_depth = cfg->rollout_num + 2;
     p.hist_cap = cfg->num_steps + 2 + 600;           // room for sc_selfplay_set_position prefixes
     p.tpos_cap = cfg->rollout_num + 2;
-    p.trace_cap = cfg->n_games;
+    p.trace_cap = cfg->trace_capacity > 0 ? std::min(cfg->n_games, std::max(cfg->trace_capacity, 2 * cfg->n_slots)) : cfg->n_games;
     p.total_games = cfg->n_games;
     const size_t G = (size_t)cfg->n_slots, NC = (size_t)p.node_cap;
     int rc = 0;
@@ -596,7 +596,8 @@ int sc_selfplay_timing(sc_selfplay* sp, int reset, float* ms_total, float* ms_nn
 
 int sc_selfplay_get_trace(sc_selfplay* sp, int game, sc_trace_info* info, uint16_t* step_move, float* step_q,
                           int32_t* child_off, uint16_t* child_move, int32_t* child_n, float* child_q, float* child_uct) {
-    if (!sp || !info || game < 0 || game >= sp->p.trace_cap) return fail("bad argument");
+    if (!sp || !info || game < 0 || game >= sp->p.total_games) return fail("bad argument");
+    game %= sp->p.trace_cap;
     HIPOK(hipSetDevice(sp->device));
     HIPOK(hipStreamSynchronize(sp->stream));
     const sc::SpParams& p = sp->p;

@@ -1,0 +1,288 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C ABI (include/sc_engine.h), against the CPU
+oracle on identical seeded inputs, against the committed golden vectors, and -- at BASELINE.json's full sizes
+(256 concurrent games, rollout 180) -- through size-independent invariants of the search.
+
+Bars: integer / index / search work is bit-exact; network outputs are within the reference's own convention
+rtol = atol = 1e-2 against the fp32 reference vectors (scripts/eval_speed.py:40-43).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from helpers import random_games
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+RTOL = ATOL = 1e-2   # reference convention, scripts/eval_speed.py:40-43
+
+
+@pytest.fixture(scope="module")
+def scamd():
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "smart-chess-rust_amd"))
+    import scamd as m
+    if m.lib().sc_device_count() <= 0:
+        pytest.fail("no MI355X visible: the HIP path cannot be tested (and there is no fallback)")
+    return m
+
+
+# ---------------------------------------------------------------------------------- rules + encoder (a10-a16)
+def test_encode_positions_bit_exact(scamd, orc):
+    games = random_games(orc, 600, 260, seed=11)
+    games += [([], orc.State())]
+    enc = scamd.encode_positions([g[0] for g in games])
+    for i, (mv, st) in enumerate(games):
+        ob, om = st.encode()
+        assert np.array_equal(enc["boards"][i], ob), (i, st.fen())
+        assert np.array_equal(enc["meta"][i], om), (i, st.fen())
+        lm = st.legal_moves()
+        assert list(enc["legal_moves"][i]) == lm, (i, st.fen())
+        assert list(enc["legal_idx"][i]) == [orc.move_index(m, st.turn) for m in lm]
+        oc = st.outcome()
+        assert scamd.TERMINATION[int(enc["termination"][i])] == (oc["termination"] if oc else None), st.fen()
+        if oc:
+            assert {1: "White", 0: "Black", -1: None}[int(enc["winner"][i])] == oc["winner"]
+        assert bool(enc["is_check"][i]) == st.is_check() and enc["status"][i] == 0
+
+
+def test_encode_reference_fixtures(scamd):
+    fx = json.load(open(os.path.join(GOLD, "ref_fixtures.json")))
+    lines, want = [[]], [fx["legal_moves_start"]]
+    played = []
+    for step in fx["trace_first10"]:
+        lines.append(list(played))
+        want.append([c[0] for c in step[2]])
+        played.append(step[0])
+    enc = scamd.encode_positions(lines)
+    for lm, w in zip(enc["legal_moves"], want):
+        assert [scamd.move_uci(m) for m in lm] == w       # python-chess order recorded by the reference
+    enc = scamd.encode_positions([fx["selfplay_moves_41"]])
+    assert enc["status"][0] == 0 and enc["meta"][0][1] == 21
+
+
+def test_encode_rejects_illegal_moves(scamd):
+    enc = scamd.encode_positions([["e2e4", "e7e5", "e1e3"], ["e2e5"]])
+    assert enc["status"][0] == -3 and enc["status"][1] == -1
+
+
+# ---------------------------------------------------------------------------------- network (a17-a19)
+@pytest.mark.parametrize("nb", [1, 10])
+def test_network_matches_reference_goldens(scamd, nb):
+    g = np.load(os.path.join(GOLD, f"nn_ref_b{nb}_c256.npz"))
+    eng = scamd.Engine(nb, 256, seed=int(g["seed"]))
+    logp, val = eng.forward(g["boards"], g["meta"])
+    np.testing.assert_allclose(logp, g["logp"], rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(val, g["value"], rtol=RTOL, atol=ATOL)
+    assert np.abs(np.exp(logp.astype(np.float64)).sum(axis=1) - 1).max() < 1e-4
+    # batch independence / determinism: same rows in a different batch composition give identical bits
+    l2, v2 = eng.forward(g["boards"][::-1], g["meta"][::-1])
+    assert np.array_equal(l2[::-1], logp) and np.array_equal(v2[::-1], val)
+    eng.close()
+
+
+@pytest.mark.parametrize("C,nb", [(128, 3), (256, 2)])
+def test_network_matches_bf16_emulating_oracle(scamd, orc, C, nb):
+    """tight check (quantisation points identical, only summation order differs); covers the build-defined
+    128-channel variant that has no reference instantiation"""
+    g = np.load(os.path.join(GOLD, "nn_ref_b1_c256.npz"))
+    eng = scamd.Engine(nb, C, seed=9)
+    net = orc.Net(nb, C, seed=9, emulate_bf16=True)
+    logp, val = eng.forward(g["boards"][:4], g["meta"][:4])
+    lat = eng.debug(g["boards"][:1], g["meta"][:1], 1000)[0]
+    for k in range(4):
+        ol, ov, olat = net.forward(g["boards"][k], g["meta"][k], latent=True)
+        assert np.abs(logp[k] - ol).max() < 2e-2 and abs(val[k] - ov) < 5e-3
+        if k == 0:
+            assert np.abs(lat - olat).max() < 5e-2 * max(1.0, np.abs(olat).max())
+    eng.close()
+
+
+def test_scw_blob_loads_like_seed_init(scamd, tmp_path):
+    import scw
+    sd = scw.prng_state_dict(1, 256, 42)
+    p = str(tmp_path / "w.scw")
+    scw.write_scw(p, sd, 1, 256)
+    g = np.load(os.path.join(GOLD, "nn_ref_b1_c256.npz"))
+    a = scamd.Engine(1, 256, seed=42)
+    b = scamd.Engine(weights=p)
+    la, va = a.forward(g["boards"][:2], g["meta"][:2])
+    lb, vb = b.forward(g["boards"][:2], g["meta"][:2])
+    assert np.array_equal(la, lb) and np.array_equal(va, vb)
+
+
+def test_predict_contract(scamd, orc):
+    """Game::predict (torch.rs:89-146): steps, renormalised priors, White-view value; terminal positions"""
+    g = np.load(os.path.join(GOLD, "nn_ref_b1_c256.npz"))
+    eng = scamd.Engine(1, 256, seed=int(g["seed"]))
+    hip = scamd.ChessHip(eng)
+    net = orc.Net(1, 256, seed=int(g["seed"]))
+    for line in (["e2e4", "e7e5"], ["d2d4", "g8f6", "c2c4"], []):
+        steps, pri, val = hip.predict(line)
+        st = orc.State()
+        for m in line:
+            st.push(m)
+        lm = st.legal_moves()
+        assert steps == lm
+        b, m = st.encode()
+        ol, ov = net.forward(b, m)
+        e = np.exp(ol[[orc.move_index(x, st.turn) for x in lm]])
+        ref = e / (e.sum() + 1e-5)
+        assert 0.5 * np.abs(pri - ref).sum() < 1e-2            # total variation distance (validate_inference.py:22-23)
+        np.testing.assert_allclose(pri, ref, rtol=5e-2, atol=1e-3)
+        assert abs(val - ov) < ATOL + RTOL * abs(ov)
+        assert abs(pri.sum() - 1) < 1e-3
+        assert hip.reverse_q(line) == (len(line) % 2 == 1)
+    steps, pri, val = hip.predict(["f2f3", "e7e5", "g2g4", "d8h4"])   # White is checkmated
+    assert steps == [] and val == -1.0
+    eng.close()
+
+
+# ---------------------------------------------------------------------------------- search (a1-a9, a20)
+def _same_tree(t, d):
+    return (len(t["n"]) == len(d["n"]) and np.array_equal(t["n"], d["n"]) and np.array_equal(t["q"], d["q"])
+            and np.array_equal(t["uct"], d["uct"]) and np.array_equal(t["move"][1:], d["move"][1:])
+            and np.array_equal(t["n_child"], d["n_child"]))
+
+
+@pytest.mark.parametrize("line", [[], ["e2e4", "c7c5", "g1f3"], ["f2f3", "e7e5", "g2g4"]])
+def test_search_lockstep_exact(scamd, orc, line):
+    """every simulation: identical node pool (N, Q sums, uct, moves) and identical path"""
+    R = 120
+    sp = scamd.SelfPlay(None, n_slots=2, n_games=2, rollout_num=R, num_steps=20, cpuct=2.5, with_noise=False,
+                        evaluator="synth", seed=3)
+    st = orc.State()
+    for m in line:
+        st.push(m)
+    sp.set_position(0, line)
+    srch = orc.Search(st)
+    for s in range(R - 1):
+        sp.enqueue(1)
+        srch.sim(cpuct=2.5, with_noise=False)
+        if s % 7 == 0 or s > R - 5:
+            t, d = sp.tree(0), srch.dump()
+            assert _same_tree(t, d), s
+            assert list(sp.slot(0)["path"]) == list(srch.last_path())
+    assert sp.stats()["error_flags"] == 0
+
+
+def test_search_with_injected_root_noise_exact(scamd, orc):
+    R = 60
+    sp = scamd.SelfPlay(None, n_slots=1, n_games=1, rollout_num=R, num_steps=10, cpuct=2.5, with_noise=True,
+                        epsilon=0.15, evaluator="synth", external_noise=True, seed=1)
+    st = orc.State()
+    srch = orc.Search(st)
+    rnd = np.random.RandomState(0)
+    for s in range(R - 1):
+        nz = rnd.dirichlet([0.3] * 20).astype(np.float32)
+        sp.set_noise(0, nz)
+        sp.enqueue(1)
+        srch.sim(cpuct=2.5, epsilon=0.15, with_noise=True, noise=nz.astype(np.float64))
+    assert _same_tree(sp.tree(0), srch.dump())
+
+
+def test_selfplay_games_exact(scamd, orc):
+    """whole games (temperature sampling in the first plies, outcome gate, slot recycling) == oracle traces"""
+    cfg = dict(rollout_num=20, num_steps=140, cpuct=2.5, temperature=0.0, temperature_switch=4, with_noise=False)
+    sp = scamd.SelfPlay(None, n_slots=8, n_games=20, evaluator="synth", seed=11, first_game_id=100, outcome_gate=100, **cfg)
+    sp.run()
+    st = sp.stats()
+    assert st["games_finished"] == 20 and st["games_active"] == 0 and st["error_flags"] == 0
+    outcomes = set()
+    for gi in range(20):
+        tr = sp.trace(gi)
+        ref = orc.selfplay_game(seed=11, game_id=tr["game_id"], outcome_gate=100, **cfg)
+        assert tr["steps"] == ref["steps"], gi
+        assert tr["outcome"] == ref["outcome"], gi
+        outcomes.add(json.dumps(tr["outcome"]))
+    assert sorted(sp.trace(g)["game_id"] for g in range(20)) == list(range(100, 120))
+    # a lower gate exercises outcome(claim_draw=True) on the device
+    sp2 = scamd.SelfPlay(None, n_slots=8, n_games=8, evaluator="synth", seed=5, outcome_gate=10, **cfg)
+    sp2.run()
+    for gi in range(8):
+        tr = sp2.trace(gi)
+        ref = orc.selfplay_game(seed=5, game_id=tr["game_id"], outcome_gate=10, **cfg)
+        assert tr["steps"] == ref["steps"] and tr["outcome"] == ref["outcome"]
+
+
+def test_trace_file_written_by_engine(scamd, orc, tmp_path):
+    sp = scamd.SelfPlay(None, n_slots=2, n_games=2, rollout_num=16, num_steps=12, evaluator="synth", with_noise=False, seed=2)
+    sp.run()
+    p = str(tmp_path / "trace0.json")
+    sp.write_trace(0, p)
+    js = json.load(open(p))
+    tr = sp.trace(0)
+    assert list(js.keys()) == ["outcome", "steps"] and js["outcome"] is None and len(js["steps"]) == 12
+    for a, b in zip(js["steps"], tr["steps"]):
+        assert a[0] == b[0] and a[1] == b[1] and [tuple(c) for c in a[2]] == [tuple(c) for c in b[2]]
+
+
+def test_root_noise_is_dirichlet(scamd):
+    """distributional parity with get_noise (mcts.rs:123-130): Dirichlet(0.3) over the 20 root moves"""
+    sp = scamd.SelfPlay(None, n_slots=64, n_games=64, rollout_num=400, num_steps=4, evaluator="synth", with_noise=True, seed=8)
+    sp.enqueue(1)
+    samples = []
+    for s in range(40):
+        sp.enqueue(1)
+        sp.sync()
+        samples += [sp.get_noise(g, 20).copy() for g in range(64)]
+    x = np.array(samples, np.float64)
+    assert np.abs(x.sum(axis=1) - 1).max() < 1e-4 and (x >= 0).all()
+    n, a = 20, 0.3
+    assert abs(x.mean() - 1 / n) < 1e-3
+    var = (1 / n) * (1 - 1 / n) / (n * a + 1)
+    assert abs(x.var(axis=0).mean() / var - 1) < 0.1
+    assert len({tuple(np.round(r, 6)) for r in x}) == len(x)        # fresh noise every simulation and game
+
+
+# ---------------------------------------------------------------------------------- full size (BASELINE cfg2)
+def test_full_size_invariants(scamd, orc):
+    """256 concurrent games, rollout 180, 10x256 bf16 net: invariants that do not need the oracle at size"""
+    eng = scamd.Engine(10, 256, seed=1)
+    R, G = 180, 256
+    sp = scamd.SelfPlay(eng, n_slots=G, n_games=100000, trace_capacity=2 * G, rollout_num=R, num_steps=150, cpuct=2.5, temperature=0.0,
+                        temperature_switch=4, epsilon=0.15, with_noise=True, seed=5)
+    sp.enqueue(R - 1)
+    sp.sync()
+    st = sp.stats()
+    assert st["error_flags"] == 0 and st["sims_done"] == G * (R - 1)
+    for g in (0, 97, 255):
+        t = sp.tree(g)
+        assert t["n"][0] == R - 1 and t["n_child"][0] == 20
+        kids = slice(t["first_child"][0], t["first_child"][0] + 20)
+        assert t["n"][kids].sum() == R - 2                          # first simulation only expands the root
+        assert abs(t["prior"][kids].sum() - 1) < 1e-3               # renormalised priors
+        assert np.isfinite(t["q"]).all() and np.abs(t["q"][0]) <= R
+        # every expanded node's children are contiguous and counted once
+        exp = np.nonzero(t["n_child"])[0]
+        assert t["n_child"][exp].sum() == len(t["n"]) - 1
+    sp.enqueue(2 * R + 1)                                           # finish ply 0 and two more plies
+    sp.sync()
+    assert all(sp.slot(g)["ply"] == 3 for g in (0, 128, 255))
+    assert sp.stats()["plies_done"] == 3 * G
+    sp.close()
+    # short complete games: traces replay legally, children are the legal moves in order, visits add up
+    sp = scamd.SelfPlay(eng, n_slots=64, n_games=64, rollout_num=32, num_steps=6, cpuct=2.5, with_noise=True, seed=6)
+    sp.run()
+    for g in range(0, 64, 9):
+        tr = sp.trace(g)
+        s = orc.State()
+        assert len(tr["steps"]) == 6 and tr["outcome"] is None
+        for mv, q, kids in tr["steps"]:
+            assert [k[0] for k in kids] == s.legal_uci() and sum(k[1] for k in kids) == 31
+            s.push(mv)
+    eng.close()
+
+
+def test_selfplay_net_is_deterministic(scamd):
+    eng = scamd.Engine(2, 128, seed=3)
+    runs = []
+    for _ in range(2):
+        sp = scamd.SelfPlay(eng, n_slots=16, n_games=16, rollout_num=24, num_steps=8, with_noise=True, seed=9)
+        sp.run()
+        runs.append([sp.trace(g) for g in range(16)])
+        sp.close()
+    assert runs[0] == runs[1]
+    eng.close()

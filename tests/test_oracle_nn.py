@@ -1,0 +1,59 @@
+"""Pins the oracle's fp32 network restatement (oracle/nn.c) to golden vectors produced by the REFERENCE
+network itself (py/module.py imported in the build container; tools/gen_golden_nn.py), and checks the
+build-owned weight generator / SCW1 blob against the oracle."""
+import os
+
+import numpy as np
+import pytest
+
+import scw
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.mark.parametrize("nb", [1, 10])
+def test_oracle_matches_reference_module(orc, nb):
+    g = np.load(os.path.join(GOLD, f"nn_ref_b{nb}_c256.npz"))
+    assert int(g["n_params"]) == {1: 3755740, 10: 14979676}[nb]
+    net = orc.Net(nb, 256, seed=int(g["seed"]))
+    for k in range(len(g["names"])):
+        logp, v = net.forward(g["boards"][k], g["meta"][k])
+        np.testing.assert_allclose(logp, g["logp"][k], rtol=0, atol=5e-5)
+        assert abs(v - g["value"][k]) < 5e-6
+        assert abs(np.exp(logp.astype(np.float64)).sum() - 1) < 1e-5
+
+
+def test_value_sign_follows_turn(orc):
+    g = np.load(os.path.join(GOLD, "nn_ref_b1_c256.npz"))
+    net = orc.Net(1, 256, seed=int(g["seed"]))
+    meta = g["meta"][0].copy()
+    _, v1 = net.forward(g["boards"][0], meta)
+    meta[0] = 1 - meta[0]
+    _, v0 = net.forward(g["boards"][0], meta)
+    assert v1 * v0 < 0                      # (2*turn-1) flip, py/module.py:147-149 (fc input changes too)
+
+
+def test_prng_weights_numpy_equals_c(orc):
+    for C in (128, 256):
+        net = orc.Net(1, C, seed=77)
+        table = scw.tensor_table(1, C)
+        assert net.num_tensors() == len(table)
+        sd = scw.prng_state_dict(1, C, 77)
+        for i, (name, shape, _, _) in enumerate(table):
+            assert net.tensor_shape(i) == tuple(shape), name
+            assert np.array_equal(net.get_tensor(i), sd[name]), name
+
+
+def test_scw_blob_roundtrip(tmp_path):
+    sd = scw.prng_state_dict(1, 128, 3)
+    p = str(tmp_path / "w.scw")
+    scw.write_scw(p, {"model." + k: v for k, v in sd.items()}, 1, 128)   # Lightning prefix is stripped
+    nb, C, sd2 = scw.read_scw(p)
+    assert (nb, C) == (1, 128) and all(np.array_equal(sd[k], sd2[k]) for k in sd)
+
+
+def test_bf16_emulation_is_close_to_fp32(orc):
+    g = np.load(os.path.join(GOLD, "nn_ref_b1_c256.npz"))
+    a = orc.Net(1, 256, seed=int(g["seed"]), emulate_bf16=True)
+    logp, v = a.forward(g["boards"][0], g["meta"][0])
+    assert np.abs(logp - g["logp"][0]).max() < 5e-2 and abs(v - g["value"][0]) < 1e-2
