@@ -59,14 +59,24 @@ def cpu_baseline(n_blocks, C, budget_s, rollout):
     ev = orc.eval_fn("orc_eval_net")
 
     def worker(i, faithful, budget):
+        # plays on from the start position: `rollout` simulations per ply, then the most visited move
         st = orc.State()
-        s = orc.Search(st)
         t0 = time.time()
-        n = 0
-        while time.time() - t0 < budget and n < rollout:
-            s.sim(evaluator=ev, user=net.h, cpuct=2.5, epsilon=0.15, with_noise=True, faithful=faithful)
-            n += 1
-        return n, s.num_evals(), time.time() - t0
+        n = evals = 0
+        while time.time() - t0 < budget:
+            s = orc.Search(st)
+            k = 0
+            while k < rollout and time.time() - t0 < budget:
+                s.sim(evaluator=ev, user=net.h, cpuct=2.5, epsilon=0.15, with_noise=True, faithful=faithful)
+                k += 1
+            n += k
+            evals += s.num_evals()
+            d = s.dump()
+            if k < rollout or d["n_child"][0] == 0:
+                break
+            kids = d["n"][d["first_child"][0]:d["first_child"][0] + d["n_child"][0]]
+            st.push(int(d["move"][d["first_child"][0] + int(kids.argmax())]))
+        return n, evals, time.time() - t0
 
     out = {}
     for name, faithful, budget in (("faithful", True, budget_s * 0.7), ("cached", False, budget_s * 0.3)):
@@ -80,9 +90,10 @@ def cpu_baseline(n_blocks, C, budget_s, rollout):
         "unit": "simulations/s",
         "cores": cores,
         "kind": "port",
-        "sample": (f"{cores} games (one per core, 1 thread each), simulations of ply 0 from the start position for "
-                   f"{budget_s * 0.7:.0f} s, fp32 {n_blocks}x{C} net re-evaluated at every path node (reference-faithful, "
-                   f"{out['faithful'][1]} net calls); CPU oracle = restatement of the reference algorithm, not the Rust binary"),
+        "sample": (f"{cores} self-play games from the start position (one per core, 1 thread each, rollout={rollout} per ply) "
+                   f"for {out['faithful'][2]:.1f} s wall, fp32 {n_blocks}x{C} net re-evaluated at every path node "
+                   f"(reference-faithful, src/mcts.rs:152; {out['faithful'][1]} net calls); CPU oracle = restatement of the "
+                   "reference algorithm, not the Rust binary"),
         "cached_prior_value": round(out["cached"][0], 2),
     }
 
