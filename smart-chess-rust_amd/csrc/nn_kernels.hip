@@ -1,12 +1,15 @@
 // nn_kernels.hip -- translation unit of the network kernels.
 #include "nn_kernels.hpp"
 
+#include <algorithm>
+
 #include "launchers.hpp"
 
 namespace scl {
 size_t tower_lds_bytes(int C) {
-    size_t cp = (size_t)C + 8, hp = scnn::HEAD + 8;
-    return 100 * cp * 2 + 64 * hp * 2 + 512 * 4 + 640 * 4 + 8 * 4;
+    size_t cp = (size_t)C + 8, hp = scnn::HEAD + 8, rp = (size_t)C + 4;
+    size_t rs = std::max<size_t>(64 * rp * 4, 64 * hp * 2);
+    return 100 * cp * 2 + rs + 512 * 4 + 640 * 4 + 8 * 4;
 }
 const char* nn_init() {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scnn::k_tower<256>),

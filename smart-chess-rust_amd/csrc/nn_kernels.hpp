@@ -52,7 +52,7 @@ __device__ inline void conv_mma(const bf16_t* __restrict__ X, int CP, const bf16
                                 f32x4 (&acc)[4][NTW]) {
     constexpr int KPT = CIN / 32;       // k-steps per tap
     constexpr int S = TAPS * KPT;       // total k-steps
-    static_assert(S % PF == 0, "k-steps must be a multiple of the prefetch depth");
+    static_assert(S % 4 == 0, "k-steps must be a multiple of the ring size");
     const int row16 = lane & 15, kq = lane >> 4;
     int abase[4];
 #pragma unroll
@@ -61,34 +61,43 @@ __device__ inline void conv_mma(const bf16_t* __restrict__ X, int CP, const bf16
         abase[mt] = (HALO ? hidx(p) : p) * CP + 8 * kq;
     }
     const bf16x8* __restrict__ Wv = reinterpret_cast<const bf16x8*>(Wp) + (size_t)(wave * NTW) * 64 + lane;
-    bf16x8 bq[PF][NTW];
+    // B: ring of 4 register slots, loads run PF = 3 k-steps ahead of the MFMAs that consume them (the slot
+    // being refilled was consumed one step earlier, so the load can issue BEFORE this step's MFMAs).  The
+    // prefetch is unconditional: the host pads the weight blob so that running 3 steps past a tensor is legal.
+    // A: double-buffered LDS fragments, one step ahead (reads past the last step land inside the LDS allocation).
+    bf16x8 bq[4][NTW];
+    bf16x8 aq[2][4];
+    auto loadB = [&](bf16x8 (&dst)[NTW], int s) {
 #pragma unroll
-    for (int u = 0; u < PF; u++)
+        for (int i = 0; i < NTW; i++) dst[i] = Wv[((size_t)s * NT_TOTAL + i) * 64];
+    };
+    auto loadA = [&](bf16x8 (&dst)[4], int s) {
+        const int tap = s / KPT, kc = s - tap * KPT;
+        const int toff = (TAPS == 9) ? ((tap / 3 - 1) * 10 + (tap % 3 - 1)) : 0;
+        const int aoff = toff * CP + kc * 32;
 #pragma unroll
-        for (int i = 0; i < NTW; i++) bq[u][i] = Wv[((size_t)u * NT_TOTAL + i) * 64];
+        for (int mt = 0; mt < 4; mt++) dst[mt] = *reinterpret_cast<const bf16x8*>(X + abase[mt] + aoff);
+    };
+    loadB(bq[0], 0);
+    loadB(bq[1], 1);
+    loadB(bq[2], 2);
+    loadA(aq[0], 0);
 #pragma unroll 1
-    for (int s0 = 0; s0 < S; s0 += PF) {
+    for (int s0 = 0; s0 < S; s0 += 4) {
 #pragma unroll
-        for (int u = 0; u < PF; u++) {
+        for (int u = 0; u < 4; u++) {
             const int s = s0 + u;
-            bf16x8 b[NTW];
-#pragma unroll
-            for (int i = 0; i < NTW; i++) b[i] = bq[u][i];
-            if (s + PF < S) {
-#pragma unroll
-                for (int i = 0; i < NTW; i++) bq[u][i] = Wv[((size_t)(s + PF) * NT_TOTAL + i) * 64];
-            }
-            const int tap = s / KPT, kc = s - tap * KPT;
-            const int toff = (TAPS == 9) ? ((tap / 3 - 1) * 10 + (tap % 3 - 1)) : 0;
-            const int aoff = toff * CP + kc * 32;
-            bf16x8 a[4];
-#pragma unroll
-            for (int mt = 0; mt < 4; mt++) a[mt] = *reinterpret_cast<const bf16x8*>(X + abase[mt] + aoff);
+            loadB(bq[(u + 3) & 3], s + PF);
+            loadA(aq[(u + 1) & 1], s + 1);
+            // pin the prefetches to THIS step: without the fence the machine scheduler sinks each load to just
+            // before its use (minimising live ranges) and the whole L2 latency is exposed on every step
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int mt = 0; mt < 4; mt++)
 #pragma unroll
                 for (int i = 0; i < NTW; i++)
-                    acc[mt][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt], b[i], acc[mt][i], 0, 0, 0);
+                    acc[mt][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[u & 1][mt], bq[u][i], acc[mt][i], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 }
@@ -217,13 +226,17 @@ __global__ __launch_bounds__(256, 1) void k_tower(TowerArgs A) {
     constexpr int CP = C + 8;          // image pixel stride (elements): +16 B skews LDS banks
     constexpr int HP = HEAD + 8;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    bf16_t* Xa = reinterpret_cast<bf16_t*>(smem);                           // [100][CP]
-    bf16_t* Xh = reinterpret_cast<bf16_t*>(smem + 100 * CP * 2);            // [64][HP]
-    float* s_stat = reinterpret_cast<float*>(smem + 100 * CP * 2 + 64 * HP * 2);  // [64][4][2]
+    constexpr int RP = C + 4;          // residual row stride (floats): +16 B skews LDS banks
+    constexpr int XA_BYTES = 100 * CP * 2;
+    constexpr int RS_BYTES = (64 * RP * 4 > 64 * HP * 2) ? 64 * RP * 4 : 64 * HP * 2;
+    bf16_t* Xa = reinterpret_cast<bf16_t*>(smem);                           // [100][CP] bf16 image (conv A operand)
+    float* Rs = reinterpret_cast<float*>(smem + XA_BYTES);                  // [64][RP] fp32 residual stream (trunk)
+    bf16_t* Xh = reinterpret_cast<bf16_t*>(smem + XA_BYTES);                // [64][HP] policy hidden; aliases Rs (heads only)
+    float* s_stat = reinterpret_cast<float*>(smem + XA_BYTES + RS_BYTES);   // [64][4][2]
     float* s_vec = s_stat + 512;                                            // pooled[256] | hidden[128] | scale[256]
     float* s_red = s_vec + 640;                                             // [8]
     float* s_z = reinterpret_cast<float*>(smem);                            // policy logits [4672], aliases Xa (after the trunk)
-    static_assert(4672 * 4 <= 100 * CP * 2 + 64 * HP * 2, "policy logits must fit in the image area");
+    static_assert(4672 * 4 <= XA_BYTES, "policy logits must fit in the image area");
 
     const int pos = blockIdx.x;
     if (pos >= A.n_pos) return;
@@ -252,7 +265,22 @@ __global__ __launch_bounds__(256, 1) void k_tower(TowerArgs A) {
     }
     __syncthreads();
 
-    f32x4 acc[4][NTW], res[4][NTW];
+    // The fp32 residual stream is parked in LDS between blocks (160 KiB/CU and one workgroup per CU make
+    // that free) so that the conv loops keep only accumulators + operand rings in registers.
+    f32x4 acc[4][NTW];
+    auto store_res = [&]() {
+        const int c0 = chan0<NTW>(wave, lane);
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                float* d = Rs + (mt * 16 + (lane >> 4) * 4 + r) * RP + c0;
+                if (NTW == 4)
+                    *reinterpret_cast<float4*>(d) = make_float4(acc[mt][0][r], acc[mt][1][r], acc[mt][2][r], acc[mt][3][r]);
+                else
+                    *reinterpret_cast<float2*>(d) = make_float2(acc[mt][0][r], acc[mt][1][r]);
+            }
+    };
     auto zero_acc = [&]() {
 #pragma unroll
         for (int mt = 0; mt < 4; mt++)
@@ -267,12 +295,8 @@ __global__ __launch_bounds__(256, 1) void k_tower(TowerArgs A) {
         const float* f = net.wf + net.f_stem;
         bias_layernorm<NTW>(acc, f, f + C, f + 2 * C, C, true, wave, lane, s_stat);
     }
-#pragma unroll
-    for (int mt = 0; mt < 4; mt++)
-#pragma unroll
-        for (int i = 0; i < NTW; i++) res[mt][i] = acc[mt][i];
-    __syncthreads();  // all waves finished reading the input image
-    store_image<NTW, true>(acc, Xa, CP, wave, lane);
+    store_res();
+    store_image<NTW, true>(acc, Xa, CP, wave, lane);  // every wave passed the LN barriers: the input image is dead
     __syncthreads();
     auto dump = [&](int stage) {
         if (A.dbg && A.dbg_stage == stage) {
@@ -283,7 +307,7 @@ __global__ __launch_bounds__(256, 1) void k_tower(TowerArgs A) {
                 for (int r = 0; r < 4; r++)
 #pragma unroll
                     for (int i = 0; i < NTW; i++)
-                        A.dbg[((size_t)pos * 64 + mt * 16 + (lane >> 4) * 4 + r) * C + c0 + i] = res[mt][i][r];
+                        A.dbg[((size_t)pos * 64 + mt * 16 + (lane >> 4) * 4 + r) * C + c0 + i] = acc[mt][i][r];
         }
     };
     dump(0);
@@ -297,7 +321,6 @@ __global__ __launch_bounds__(256, 1) void k_tower(TowerArgs A) {
         zero_acc();
         conv_mma<C, 9, NTW, NT, true>(Xa, CP, wb, wave, lane, acc);
         bias_layernorm<NTW>(acc, wf, wf + C, wf + 2 * C, C, true, wave, lane, s_stat);
-        __syncthreads();
         store_image<NTW, true>(acc, Xa, CP, wave, lane);
         __syncthreads();
         // conv2 -> LN
@@ -368,15 +391,24 @@ __global__ __launch_bounds__(256, 1) void k_tower(TowerArgs A) {
 #pragma unroll
             for (int mt = 0; mt < 4; mt++)
 #pragma unroll
-                for (int i = 0; i < NTW; i++)
-#pragma unroll
-                    for (int r = 0; r < 4; r++) {
-                        float y = acc[mt][i][r] * scl[i] + res[mt][i][r];
-                        y = y > 0.f ? y : 0.f;
-                        res[mt][i][r] = y;
-                        acc[mt][i][r] = y;
+                for (int r = 0; r < 4; r++) {
+                    const float* rp = Rs + (mt * 16 + (lane >> 4) * 4 + r) * RP + c0;
+                    float rv[NTW];
+                    if (NTW == 4) {
+                        float4 t = *reinterpret_cast<const float4*>(rp);
+                        rv[0] = t.x; rv[1] = t.y; rv[NTW - 2] = t.z; rv[NTW - 1] = t.w;
+                    } else {
+                        float2 t = *reinterpret_cast<const float2*>(rp);
+                        rv[0] = t.x; rv[1] = t.y;
                     }
+#pragma unroll
+                    for (int i = 0; i < NTW; i++) {
+                        float y = acc[mt][i][r] * scl[i] + rv[i];
+                        acc[mt][i][r] = y > 0.f ? y : 0.f;
+                    }
+                }
         }
+        store_res();                                      // each lane rewrites exactly the cells it just read
         store_image<NTW, true>(acc, Xa, CP, wave, lane);  // conv2 finished reading Xa before the SE barriers
         __syncthreads();
         dump(b + 1);

@@ -12,7 +12,7 @@ constexpr int HEAD = 256;      // head width (py/module.py:71,86)
 constexpr int POL_PAD = 128;   // 73 policy channels padded to 8 MFMA column tiles
 constexpr int FC1_N = 128;
 constexpr int FC1_K = 64 * HEAD;  // 16384 (+7 meta handled in k_value_finish)
-constexpr int PF = 4;             // weight prefetch ring depth (k-steps)
+constexpr int PF = 3;             // weight prefetch distance (k-steps); kernels may read PF steps past a tensor
 
 struct NetDev : NetLayout {
     const bf16_t* wb;  // packed bf16 GEMM operands

@@ -166,6 +166,7 @@ inline Packed pack(const HostWeights& w) {
     L.o_pconv1 = ob; ob += (size_t)C * H;
     L.o_pconv2 = ob; ob += (size_t)H * 128;
     L.o_fc1 = ob; ob += (size_t)64 * H * 128;
+    ob += (size_t)4 * 16 * 64 * 8;  // slack: kernels prefetch up to 3 k-steps (x16 column tiles) past a tensor
     L.f_stem = of; of += 3 * C;
     L.f_blocks = of; L.blk_stride_f = (size_t)6 * C + C / 2 + C; of += L.blk_stride_f * nb;
     L.f_vhead = of; of += 3 * H;
