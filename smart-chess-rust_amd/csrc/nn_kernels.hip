@@ -7,9 +7,9 @@
 
 namespace scl {
 size_t tower_lds_bytes(int C) {
-    size_t cp = (size_t)C + 8, hp = scnn::HEAD + 8, rp = (size_t)C + 4;
+    size_t cp = (size_t)C + 16, hp = scnn::HEAD + 16, rp = (size_t)C + 4;
     size_t rs = std::max<size_t>(64 * rp * 4, 64 * hp * 2);
-    return 100 * cp * 2 + rs + 512 * 4 + 640 * 4 + 8 * 4;
+    return 100 * cp * 2 + rs + 512 * 4 + 640 * 4 + 8 * 4 + 4 * 64 * 8;
 }
 const char* nn_init() {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scnn::k_tower<256>),

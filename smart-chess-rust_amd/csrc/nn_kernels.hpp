@@ -41,64 +41,98 @@ __device__ inline float bf2f(bf16_t u) { return __builtin_bit_cast(float, (uint3
 
 // haloed image index of pixel p (0..63)
 __device__ inline int hidx(int p) { return ((p >> 3) + 1) * 10 + (p & 7) + 1; }
+// GEMM row (0..63) -> board pixel.  Rows 8..15 of every 16-row MFMA tile take the files of their rank rotated
+// by 6: together with the 32-byte row padding of the LDS image this makes the 16 (row, k-quarter) addresses of
+// every ds_read_b128 lane group fall on 16 distinct 16-byte bank slots (conflict-free A-operand reads; a plain
+// row = pixel mapping is 2-way conflicted for every padding because of the halo gap between ranks).
+__device__ inline int row2pix(int row) {
+    int j = (row >> 3) & 1, f = row & 7;
+    return (row & ~7) | ((f + 6 * j) & 7);
+}
 
 // --------------------------------------------------------------------------------------------
 // Implicit GEMM: acc[mt][i] += A(64 x K) * B(K x 16*NTW*4) for this wave's NTW column tiles.
 //   A: LDS image, pixel stride `CP` elements (haloed when TAPS==9, plain [64] rows when !HALO)
 //   B: global, packed [kstep][ntile_total][lane][8]
 // K = TAPS*CIN, k-step = 32.
-template <int CIN, int TAPS, int NTW, int NT_TOTAL, bool HALO>
-__device__ inline void conv_mma(const bf16_t* __restrict__ X, int CP, const bf16_t* __restrict__ Wp, int wave, int lane,
-                                f32x4 (&acc)[4][NTW]) {
-    constexpr int KPT = CIN / 32;       // k-steps per tap
-    constexpr int S = TAPS * KPT;       // total k-steps
-    static_assert(S % 4 == 0, "k-steps must be a multiple of the ring size");
+// All LDS accesses of the conv loop go through this symbol so that the compiler keeps them in the LDS address
+// space (ds_read_b128); pointers carried through the tap loop degrade to flat loads, which also poison vmcnt.
+extern __shared__ __attribute__((aligned(16))) unsigned char g_smem[];
+
+__device__ __forceinline__ bf16x8 lds_frag(int byte_off) { return *reinterpret_cast<const bf16x8*>(g_smem + byte_off); }
+
+// 16-byte weight fragment through a wave-uniform buffer descriptor: voffset = lane*16 (loop invariant),
+// soffset = scalar cursor, imm = column-tile offset -> zero vector ALU per load.
+__device__ __forceinline__ bf16x8 wload(__amdgpu_buffer_rsrc_t rsrc, int voff, int soff) {
+    typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+    u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0);
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+// xoff: byte offset of the image inside g_smem.
+template <int CIN, int TAPS, int NTW, int NT_TOTAL, bool HALO, int CP>
+__device__ __forceinline__ void conv_mma(int xoff, const bf16_t* __restrict__ Wp, int wave_u, int lane, f32x4 (&acc)[4][NTW]) {
+    constexpr int KPT = CIN / 32;          // k-steps per tap
+    constexpr int SBB = NT_TOTAL * 1024;   // bytes per k-step of packed weights
+    static_assert(KPT % 4 == 0, "k-steps per tap must be a multiple of the ring size");
     const int row16 = lane & 15, kq = lane >> 4;
-    int abase[4];
+    // LDS byte offsets of this lane's 4 A rows at the CURRENT tap; k offsets inside a tap are immediates
+    int pa[4];
 #pragma unroll
     for (int mt = 0; mt < 4; mt++) {
-        int p = mt * 16 + row16;
-        abase[mt] = (HALO ? hidx(p) : p) * CP + 8 * kq;
+        int row = mt * 16 + row16;
+        pa[mt] = xoff + (((HALO ? hidx(row2pix(row)) : row) + (TAPS == 9 ? -11 : 0)) * CP + 8 * kq) * 2;
     }
-    const bf16x8* __restrict__ Wv = reinterpret_cast<const bf16x8*>(Wp) + (size_t)(wave * NTW) * 64 + lane;
-    // B: ring of 4 register slots, loads run PF = 3 k-steps ahead of the MFMAs that consume them (the slot
-    // being refilled was consumed one step earlier, so the load can issue BEFORE this step's MFMAs).  The
-    // prefetch is unconditional: the host pads the weight blob so that running 3 steps past a tensor is legal.
-    // A: double-buffered LDS fragments, one step ahead (reads past the last step land inside the LDS allocation).
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<bf16_t*>(Wp) + (size_t)wave_u * NTW * 512, 0, 0x7fffffff, 0x00020000);
+    const int voff = lane * 16;
+    // B: ring of 4 register slots, loads run PF = 3 k-steps ahead of the MFMAs that consume them (the slot being
+    // refilled was consumed one step earlier).  The prefetch is unconditional: the host pads the weight blob so
+    // that running 3 steps past a tensor is legal.  A: double-buffered LDS fragments, one step ahead (reads past
+    // the last step land inside the LDS allocation).
     bf16x8 bq[4][NTW];
     bf16x8 aq[2][4];
-    auto loadB = [&](bf16x8 (&dst)[NTW], int s) {
 #pragma unroll
-        for (int i = 0; i < NTW; i++) dst[i] = Wv[((size_t)s * NT_TOTAL + i) * 64];
-    };
-    auto loadA = [&](bf16x8 (&dst)[4], int s) {
-        const int tap = s / KPT, kc = s - tap * KPT;
-        const int toff = (TAPS == 9) ? ((tap / 3 - 1) * 10 + (tap % 3 - 1)) : 0;
-        const int aoff = toff * CP + kc * 32;
+    for (int st = 0; st < PF; st++)
 #pragma unroll
-        for (int mt = 0; mt < 4; mt++) dst[mt] = *reinterpret_cast<const bf16x8*>(X + abase[mt] + aoff);
-    };
-    loadB(bq[0], 0);
-    loadB(bq[1], 1);
-    loadB(bq[2], 2);
-    loadA(aq[0], 0);
+        for (int i = 0; i < NTW; i++) bq[st][i] = wload(rsrc, voff + i * 1024, st * SBB);
+#pragma unroll
+    for (int mt = 0; mt < 4; mt++) aq[0][mt] = lds_frag(pa[mt]);
+    int dxc = 0;   // tap % 3
+    int wcur = 0;  // scalar byte cursor of the current tap's first k-step
 #pragma unroll 1
-    for (int s0 = 0; s0 < S; s0 += 4) {
+    for (int tap = 0; tap < TAPS; tap++) {
+        // image offset of the next tap relative to this one: taps walk (dy,dx) row-major over the 10-wide halo image
+        const int tstep = (TAPS == 9) ? (dxc == 2 ? 8 : 1) * CP * 2 : 0;
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int s = s0 + u;
-            loadB(bq[(u + 3) & 3], s + PF);
-            loadA(aq[(u + 1) & 1], s + 1);
-            // pin the prefetches to THIS step: without the fence the machine scheduler sinks each load to just
-            // before its use (minimising live ranges) and the whole L2 latency is exposed on every step
-            __builtin_amdgcn_sched_barrier(0);
+        for (int kc = 0; kc < KPT; kc++) {
+            const int u = kc & 3;
+#pragma unroll
+            for (int i = 0; i < NTW; i++) bq[(u + 3) & 3][i] = wload(rsrc, voff + i * 1024, wcur + (kc + PF) * SBB);
+#pragma unroll
+            for (int mt = 0; mt < 4; mt++)
+                aq[(kc + 1) & 1][mt] = (kc + 1 < KPT) ? lds_frag(pa[mt] + (kc + 1) * 64) : lds_frag(pa[mt] + tstep);
 #pragma unroll
             for (int mt = 0; mt < 4; mt++)
 #pragma unroll
                 for (int i = 0; i < NTW; i++)
-                    acc[mt][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[u & 1][mt], bq[u][i], acc[mt][i], 0, 0, 0);
+                    acc[mt][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[kc & 1][mt], bq[u][i], acc[mt][i], 0, 0, 0);
+            // Issue order inside the step: one m-tile of MFMAs, then one LDS read and one weight load, ... so the
+            // matrix pipe never waits behind a burst of 8 memory instructions; the fence keeps every prefetch in
+            // the step it was written in (otherwise the scheduler sinks loads to just before their use and the
+            // whole L2 latency is exposed on every step).
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                __builtin_amdgcn_sched_group_barrier(0x008, NTW, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                if (g < NTW) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
+        wcur += KPT * SBB;
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++) pa[mt] += tstep;
+        dxc = dxc == 2 ? 0 : dxc + 1;
     }
 }
 
@@ -130,10 +164,13 @@ template <int NTW>
 __device__ inline int chan0(int wave, int lane) { return wave * (16 * NTW) + (lane & 15) * NTW; }
 
 // bias add + LayerNorm over `count` channels (eps 1e-6, timm LayerNorm2d) + optional ReLU, in place.
-// s_stat: LDS [64 rows][4 waves][2].
+// s_stat: LDS [64 rows][4 waves] float2 partial (sum, sumsq); s_mr: LDS [4 waves][64 rows] float2 (mean, rstd).
+// Row sums over the wave's columns use a halving butterfly over the 16 lanes that share a row group: 15 shuffles
+// per statistic instead of 64, and lane c of each group ends up owning row t = c of its group's 16 rows.
 template <int NTW>
 __device__ inline void bias_layernorm(f32x4 (&acc)[4][NTW], const float* __restrict__ bias, const float* __restrict__ gamma,
-                                      const float* __restrict__ beta, int count, bool relu, int wave, int lane, float* s_stat) {
+                                      const float* __restrict__ beta, int count, bool relu, int wave, int lane, float* s_stat,
+                                      float* s_mr) {
     const int c0 = chan0<NTW>(wave, lane);
     float bv[NTW], gv[NTW], ev[NTW];
 #pragma unroll
@@ -142,7 +179,7 @@ __device__ inline void bias_layernorm(f32x4 (&acc)[4][NTW], const float* __restr
         gv[i] = gamma[c0 + i];
         ev[i] = beta[c0 + i];
     }
-    float sum[4][4], sq[4][4];
+    float sm[16], sq[16];  // index t = mt*4 + r
 #pragma unroll
     for (int mt = 0; mt < 4; mt++)
 #pragma unroll
@@ -155,57 +192,62 @@ __device__ inline void bias_layernorm(f32x4 (&acc)[4][NTW], const float* __restr
                 s += v;
                 q += v * v;
             }
-#pragma unroll
-            for (int o = 1; o < 16; o <<= 1) {
-                s += __shfl_xor(s, o, 64);
-                q += __shfl_xor(q, o, 64);
-            }
-            sum[mt][r] = s;
-            sq[mt][r] = q;
+            sm[mt * 4 + r] = s;
+            sq[mt * 4 + r] = q;
         }
-    __syncthreads();  // previous users of s_stat are done
-    if ((lane & 15) == 0) {
 #pragma unroll
-        for (int mt = 0; mt < 4; mt++)
+    for (int w = 8; w >= 1; w >>= 1) {
+        const bool hi = (lane & w) != 0;
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                int row = mt * 16 + (lane >> 4) * 4 + r;
-                reinterpret_cast<float2*>(s_stat)[row * 4 + wave] = make_float2(sum[mt][r], sq[mt][r]);
-            }
+        for (int t = 0; t < w; t++) {
+            float send_s = hi ? sm[t] : sm[t + w], keep_s = hi ? sm[t + w] : sm[t];
+            float send_q = hi ? sq[t] : sq[t + w], keep_q = hi ? sq[t + w] : sq[t];
+            sm[t] = keep_s + __shfl_xor(send_s, w, 64);
+            sq[t] = keep_q + __shfl_xor(send_q, w, 64);
+        }
     }
+    const int t_own = lane & 15;
+    const int row_own = (t_own >> 2) * 16 + (lane >> 4) * 4 + (t_own & 3);
+    __syncthreads();  // previous users of s_stat are done
+    reinterpret_cast<float2*>(s_stat)[row_own * 4 + wave] = make_float2(sm[0], sq[0]);
     __syncthreads();
-    const float inv = 1.0f / (float)count;
+    {
+        const float4* st = reinterpret_cast<const float4*>(s_stat) + row_own * 2;
+        float4 a = st[0], b = st[1];
+        float s = (a.x + a.z) + (b.x + b.z);
+        float q = (a.y + a.w) + (b.y + b.w);
+        const float inv = 1.0f / (float)count;
+        float mean = s * inv;
+        float var = q * inv - mean * mean;
+        var = var < 0.f ? 0.f : var;
+        float rstd = 1.0f / sqrtf(var + 1e-6f);
+        // wave-private broadcast through LDS (DS ops of one wave execute in order; no barrier needed)
+        reinterpret_cast<float2*>(s_mr)[wave * 64 + row_own] = make_float2(mean, rstd);
+    }
 #pragma unroll
     for (int mt = 0; mt < 4; mt++)
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             int row = mt * 16 + (lane >> 4) * 4 + r;
-            const float4* st = reinterpret_cast<const float4*>(s_stat) + row * 2;
-            float4 a = st[0], b = st[1];
-            float s = (a.x + a.z) + (b.x + b.z);
-            float q = (a.y + a.w) + (b.y + b.w);
-            float mean = s * inv;
-            float var = q * inv - mean * mean;
-            var = var < 0.f ? 0.f : var;
-            float rstd = 1.0f / sqrtf(var + 1e-6f);
+            float2 mr = reinterpret_cast<const float2*>(s_mr)[wave * 64 + row];
 #pragma unroll
             for (int i = 0; i < NTW; i++) {
-                float y = (acc[mt][i][r] - mean) * rstd * gv[i] + ev[i];
+                float y = (acc[mt][i][r] - mr.x) * mr.y * gv[i] + ev[i];
                 acc[mt][i][r] = (relu && y < 0.f) ? 0.f : y;
             }
         }
 }
 
-// store the accumulator tile as bf16 into an LDS image (pixel stride CP elements)
-template <int NTW, bool HALO>
-__device__ inline void store_image(const f32x4 (&acc)[4][NTW], bf16_t* X, int CP, int wave, int lane) {
+// store the accumulator tile as bf16 into an LDS image (pixel stride CP elements; plain row index when !HALO)
+template <int NTW, bool HALO, int CP>
+__device__ inline void store_image(const f32x4 (&acc)[4][NTW], bf16_t* X, int wave, int lane) {
     const int c0 = chan0<NTW>(wave, lane);
 #pragma unroll
     for (int mt = 0; mt < 4; mt++)
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-            int p = mt * 16 + (lane >> 4) * 4 + r;
-            bf16_t* dst = X + (HALO ? hidx(p) : p) * CP + c0;
+            int row = mt * 16 + (lane >> 4) * 4 + r;
+            bf16_t* dst = X + (HALO ? hidx(row2pix(row)) : row) * CP + c0;
             if (NTW == 4) {
                 uint2 v;
                 v.x = (uint32_t)f2bf(acc[mt][0][r]) | ((uint32_t)f2bf(acc[mt][1][r]) << 16);
@@ -223,9 +265,9 @@ template <int C>
 __global__ __launch_bounds__(256, 1) void k_tower(TowerArgs A) {
     constexpr int NTW = C / 64;        // column tiles per wave in the trunk (4 or 2)
     constexpr int NT = C / 16;
-    constexpr int CP = C + 8;          // image pixel stride (elements): +16 B skews LDS banks
-    constexpr int HP = HEAD + 8;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int CP = C + 16;         // image pixel stride (elements): +32 B, see row2pix()
+    constexpr int HP = HEAD + 16;
+    unsigned char* smem = g_smem;
     constexpr int RP = C + 4;          // residual row stride (floats): +16 B skews LDS banks
     constexpr int XA_BYTES = 100 * CP * 2;
     constexpr int RS_BYTES = (64 * RP * 4 > 64 * HP * 2) ? 64 * RP * 4 : 64 * HP * 2;
@@ -235,12 +277,14 @@ __global__ __launch_bounds__(256, 1) void k_tower(TowerArgs A) {
     float* s_stat = reinterpret_cast<float*>(smem + XA_BYTES + RS_BYTES);   // [64][4][2]
     float* s_vec = s_stat + 512;                                            // pooled[256] | hidden[128] | scale[256]
     float* s_red = s_vec + 640;                                             // [8]
+    float* s_mr = s_red + 8;                                                // [4 waves][64] (mean, rstd)
     float* s_z = reinterpret_cast<float*>(smem);                            // policy logits [4672], aliases Xa (after the trunk)
     static_assert(4672 * 4 <= XA_BYTES, "policy logits must fit in the image area");
 
     const int pos = blockIdx.x;
     if (pos >= A.n_pos) return;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform: scalar addressing of the weights
     const NetDev& net = A.net;
 
     // ---- zero the image (halo stays zero for the whole kernel), then load the 112 input planes
@@ -290,13 +334,13 @@ __global__ __launch_bounds__(256, 1) void k_tower(TowerArgs A) {
 
     // ---- conv_block (py/module.py:120-126): conv3x3 112->C (K padded to 128/tap), LN, ReLU
     zero_acc();
-    conv_mma<128, 9, NTW, NT, true>(Xa, CP, net.wb + net.o_stem, wave, lane, acc);
+    conv_mma<128, 9, NTW, NT, true, CP>(0, net.wb + net.o_stem, wave, lane, acc);
     {
         const float* f = net.wf + net.f_stem;
-        bias_layernorm<NTW>(acc, f, f + C, f + 2 * C, C, true, wave, lane, s_stat);
+        bias_layernorm<NTW>(acc, f, f + C, f + 2 * C, C, true, wave, lane, s_stat, s_mr);
     }
     store_res();
-    store_image<NTW, true>(acc, Xa, CP, wave, lane);  // every wave passed the LN barriers: the input image is dead
+    store_image<NTW, true, CP>(acc, Xa, wave, lane);  // every wave passed the LN barriers: the input image is dead
     __syncthreads();
     auto dump = [&](int stage) {
         if (A.dbg && A.dbg_stage == stage) {
@@ -307,7 +351,7 @@ __global__ __launch_bounds__(256, 1) void k_tower(TowerArgs A) {
                 for (int r = 0; r < 4; r++)
 #pragma unroll
                     for (int i = 0; i < NTW; i++)
-                        A.dbg[((size_t)pos * 64 + mt * 16 + (lane >> 4) * 4 + r) * C + c0 + i] = acc[mt][i][r];
+                        A.dbg[((size_t)pos * 64 + row2pix(mt * 16 + (lane >> 4) * 4 + r)) * C + c0 + i] = acc[mt][i][r];
         }
     };
     dump(0);
@@ -319,14 +363,14 @@ __global__ __launch_bounds__(256, 1) void k_tower(TowerArgs A) {
         const float* wf = net.wf + net.f_blocks + (size_t)b * net.blk_stride_f;
         // conv1 -> LN -> ReLU
         zero_acc();
-        conv_mma<C, 9, NTW, NT, true>(Xa, CP, wb, wave, lane, acc);
-        bias_layernorm<NTW>(acc, wf, wf + C, wf + 2 * C, C, true, wave, lane, s_stat);
-        store_image<NTW, true>(acc, Xa, CP, wave, lane);
+        conv_mma<C, 9, NTW, NT, true, CP>(0, wb, wave, lane, acc);
+        bias_layernorm<NTW>(acc, wf, wf + C, wf + 2 * C, C, true, wave, lane, s_stat, s_mr);
+        store_image<NTW, true, CP>(acc, Xa, wave, lane);
         __syncthreads();
         // conv2 -> LN
         zero_acc();
-        conv_mma<C, 9, NTW, NT, true>(Xa, CP, wb + (size_t)9 * C * C, wave, lane, acc);
-        bias_layernorm<NTW>(acc, wf + 3 * C, wf + 4 * C, wf + 5 * C, C, false, wave, lane, s_stat);
+        conv_mma<C, 9, NTW, NT, true, CP>(0, wb + (size_t)9 * C * C, wave, lane, acc);
+        bias_layernorm<NTW>(acc, wf + 3 * C, wf + 4 * C, wf + 5 * C, C, false, wave, lane, s_stat, s_mr);
         // squeeze-excitation: global average pool over the 64 pixels
         {
             float cs[NTW];
@@ -409,7 +453,7 @@ __global__ __launch_bounds__(256, 1) void k_tower(TowerArgs A) {
                 }
         }
         store_res();                                      // each lane rewrites exactly the cells it just read
-        store_image<NTW, true>(acc, Xa, CP, wave, lane);  // conv2 finished reading Xa before the SE barriers
+        store_image<NTW, true, CP>(acc, Xa, wave, lane);  // conv2 finished reading Xa before the SE barriers
         __syncthreads();
         dump(b + 1);
     }
@@ -422,15 +466,15 @@ __global__ __launch_bounds__(256, 1) void k_tower(TowerArgs A) {
         for (int mt = 0; mt < 4; mt++)
 #pragma unroll
             for (int i = 0; i < 4; i++) hv[mt][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        conv_mma<C, 1, 4, 16, true>(Xa + 0, CP, net.wb + net.o_vconv, wave, lane, hv);
+        conv_mma<C, 1, 4, 16, true, CP>(0, net.wb + net.o_vconv, wave, lane, hv);
         const float* f = net.wf + net.f_vhead;
-        bias_layernorm<4>(hv, f, f + HEAD, f + 2 * HEAD, HEAD, true, wave, lane, s_stat);
+        bias_layernorm<4>(hv, f, f + HEAD, f + 2 * HEAD, HEAD, true, wave, lane, s_stat, s_mr);
         const int c0 = chan0<4>(wave, lane);
 #pragma unroll
         for (int mt = 0; mt < 4; mt++)
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                int p = mt * 16 + (lane >> 4) * 4 + r;
+                int p = row2pix(mt * 16 + (lane >> 4) * 4 + r);
                 uint2 v;
                 v.x = (uint32_t)f2bf(hv[mt][0][r]) | ((uint32_t)f2bf(hv[mt][1][r]) << 16);
                 v.y = (uint32_t)f2bf(hv[mt][2][r]) | ((uint32_t)f2bf(hv[mt][3][r]) << 16);
@@ -444,10 +488,10 @@ __global__ __launch_bounds__(256, 1) void k_tower(TowerArgs A) {
         for (int mt = 0; mt < 4; mt++)
 #pragma unroll
             for (int i = 0; i < 4; i++) hp[mt][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        conv_mma<C, 1, 4, 16, true>(Xa, CP, net.wb + net.o_pconv1, wave, lane, hp);
+        conv_mma<C, 1, 4, 16, true, CP>(0, net.wb + net.o_pconv1, wave, lane, hp);
         const float* f = net.wf + net.f_phead1;
-        bias_layernorm<4>(hp, f, f + HEAD, f + 2 * HEAD, HEAD, false, wave, lane, s_stat);
-        store_image<4, false>(hp, Xh, HP, wave, lane);
+        bias_layernorm<4>(hp, f, f + HEAD, f + 2 * HEAD, HEAD, false, wave, lane, s_stat, s_mr);
+        store_image<4, false, HP>(hp, Xh, wave, lane);
     }
     __syncthreads();
     {
@@ -456,10 +500,10 @@ __global__ __launch_bounds__(256, 1) void k_tower(TowerArgs A) {
         for (int mt = 0; mt < 4; mt++)
 #pragma unroll
             for (int i = 0; i < 2; i++) z[mt][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        conv_mma<HEAD, 1, 2, 8, false>(Xh, HP, net.wb + net.o_pconv2, wave, lane, z);
+        conv_mma<HEAD, 1, 2, 8, false, HP>(XA_BYTES, net.wb + net.o_pconv2, wave, lane, z);
         const float* f = net.wf + net.f_phead2;
         // padded channels (>=73) have zero weights, bias, gamma, beta: they add 0 to both LN sums
-        bias_layernorm<2>(z, f, f + POL_PAD, f + 2 * POL_PAD, 73, false, wave, lane, s_stat);
+        bias_layernorm<2>(z, f, f + POL_PAD, f + 2 * POL_PAD, 73, false, wave, lane, s_stat, s_mr);
         __syncthreads();  // everyone is done with Xa/Xh: the logits may overwrite the image area
         const int c0 = chan0<2>(wave, lane);
 #pragma unroll
@@ -468,7 +512,7 @@ __global__ __launch_bounds__(256, 1) void k_tower(TowerArgs A) {
             for (int r = 0; r < 4; r++)
 #pragma unroll
                 for (int i = 0; i < 2; i++) {
-                    int ch = c0 + i, p = mt * 16 + (lane >> 4) * 4 + r;
+                    int ch = c0 + i, p = row2pix(mt * 16 + (lane >> 4) * 4 + r);
                     if (ch < 73) s_z[ch * 64 + p] = z[mt][i][r];  // Flatten is channel-major (module.py:75)
                 }
     }
