@@ -56,7 +56,7 @@ def build(force=False, verbose=False):
     cli_src = os.path.join(CSRC, "selfplay_main.cpp")
     cli = os.path.join(LIB, "sc-selfplay")
     if os.path.exists(cli_src) and (force or _newer(cli, [cli_src, so] + hdrs)):
-        _run([HIPCC, "-O2", "-std=c++17", "-x", "c++", cli_src, "-o", cli, "-L" + LIB, "-lsc_engine", "-Wl,-rpath,$ORIGIN",
+        _run(["g++", "-O2", "-std=c++17", "-pthread", cli_src, "-o", cli, "-L" + LIB, "-lsc_engine", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath-link,/opt/rocm/lib",
               "-Wl,-rpath,/opt/rocm/lib"])
     return so
 

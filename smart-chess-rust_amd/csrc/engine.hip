@@ -326,6 +326,8 @@ struct sc_selfplay {
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     bool have_span = false;
     int64_t nn_launches = 0;
+    scnn::bf16_t* d_hval = nullptr;  // value-head features of the current leaves [n_slots][64][256]
+    float* d_vpart = nullptr;        // split-K partials of value_head.ffn.0 [ksplit][n_slots][128]
 };
 
 template <class T>
@@ -424,6 +426,23 @@ int sc_selfplay_create(sc_engine* e, int device_id, const sc_selfplay_config* cf
             return rc;
         }
     }
+    if (e && cfg->evaluator == SC_EVAL_NET) {
+        if (e->ksplit > 32) return fail("ksplit > 32 unsupported by the fused value tail");
+        rc |= sp_alloc(sp, &sp->d_hval, G * 64 * 256);
+        rc |= sp_alloc(sp, &sp->d_vpart, (size_t)e->ksplit * G * 128);
+        if (rc) {
+            sc_selfplay_destroy(sp);
+            return fail("self-play allocation failed", -2);
+        }
+        p.vf_fused = 1;
+        p.vf_ksplit = e->ksplit;
+        p.vpart = sp->d_vpart;
+        p.vf_w = e->d_wf;
+        p.vf_fc1b = (uint32_t)e->net.f_fc1b;
+        p.vf_fc1m = (uint32_t)e->net.f_fc1m;
+        p.vf_fc2w = (uint32_t)e->net.f_fc2w;
+        p.vf_fc2b = (uint32_t)e->net.f_fc2b;
+    }
     scl::init_slots(p, sp->stream);
     HIPOK(hipGetLastError());
     HIPOK(hipStreamSynchronize(sp->stream));
@@ -466,7 +485,8 @@ int sc_selfplay_enqueue_sims(sc_selfplay* sp, int n) {
         sp->have_span = true;
     }
     for (int i = 0; i < n; i++) {
-        scl::select(p, s);
+        // finish the previous simulation (expand/backward/ply transition) and select + encode the next leaf
+        scl::mcts(p, 1, 1, s);
         if (p.evaluator == SC_EVAL_SYNTH) {
             scl::synth_eval(p, s);
         } else {
@@ -489,7 +509,7 @@ int sc_selfplay_enqueue_sims(sc_selfplay* sp, int n) {
             t.n_legal = p.n_legal;
             t.prior = p.prior;
             t.logp = nullptr;
-            t.hval = e->d_hval;
+            t.hval = sp->d_hval;
             t.dbg = nullptr;
             t.dbg_stage = -1;
             scl::tower(t, s);
@@ -501,22 +521,13 @@ int sc_selfplay_enqueue_sims(sc_selfplay* sp, int n) {
             f.net = e->net;
             f.n_pos = p.n_slots;
             f.ksplit = e->ksplit;
-            f.hval = e->d_hval;
-            f.vpart = e->d_vpart;
-            scl::value_fc1(f, s);
-            scnn::VfinArgs v{};
-            v.net = e->net;
-            v.n_pos = p.n_slots;
-            v.ksplit = e->ksplit;
-            v.vpart = e->d_vpart;
-            v.meta = p.meta;
-            v.meta_stride = 8;
-            v.value = p.value;
-            scl::value_finish(v, s);
+            f.hval = sp->d_hval;
+            f.vpart = sp->d_vpart;
+            scl::value_fc1(f, s);   // the tail of the value head is fused into the next k_mcts launch
             sp->nn_launches++;
         }
-        scl::expand_backup(p, s);
     }
+    if (n > 0) scl::mcts(p, 1, 0, s);  // leave every game fully backed up
     sp->sim_steps_enqueued += n;
     if (sp->timing_stride > 0) HIPOK(hipEventRecord(sp->ev_end, s));
     HIPOK(hipGetLastError());

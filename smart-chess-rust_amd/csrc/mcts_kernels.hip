@@ -6,9 +6,10 @@
 
 namespace scl {
 void init_slots(const sc::SpParams& p, hipStream_t s) { hipLaunchKernelGGL(sc::k_init_slots, dim3(p.n_slots), dim3(64), 0, s, p); }
-void select(const sc::SpParams& p, hipStream_t s) { hipLaunchKernelGGL(sc::k_select, dim3(p.n_slots), dim3(64), 0, s, p); }
+void mcts(const sc::SpParams& p, int do_expand, int do_select, hipStream_t s) {
+    hipLaunchKernelGGL(sc::k_mcts, dim3(p.n_slots), dim3(64), 0, s, p, do_expand, do_select);
+}
 void synth_eval(const sc::SpParams& p, hipStream_t s) { hipLaunchKernelGGL(sc::k_synth_eval, dim3(p.n_slots), dim3(64), 0, s, p); }
-void expand_backup(const sc::SpParams& p, hipStream_t s) { hipLaunchKernelGGL(sc::k_expand_backup, dim3(p.n_slots), dim3(64), 0, s, p); }
 void set_position(const sc::SpParams& p, int slot, const uint16_t* d_moves, int n_moves, hipStream_t s) {
     hipLaunchKernelGGL(sc::k_set_position, dim3(1), dim3(64), 0, s, p, slot, d_moves, n_moves);
 }

@@ -151,11 +151,8 @@ __device__ inline float gamma03(uint64_t st) {
 }
 
 // ------------------------------------------------------------------ select (src/mcts.rs:132-227)
-__global__ __launch_bounds__(64) void k_select(SpParams p) {
-    const int g = blockIdx.x, lane = threadIdx.x;
-    __shared__ __attribute__((aligned(16))) int8_t s_stage[7168];
-    __shared__ move_t s_moves[MAXC];
-    __shared__ Position s_leaf;
+__device__ __noinline__ void dev_select(const SpParams& p, int g, int lane, int8_t* s_stage, move_t* s_moves, Position* s_leaf_p) {
+    Position& s_leaf = *s_leaf_p;
     GameCtl& c = p.ctl[g];
     if (c.status != ST_ACTIVE) {
         if (lane == 0) c.leaf_kind = LK_NONE;
@@ -430,8 +427,41 @@ __device__ inline void finish_game(SpParams& p, int g, int lane, int has_outcome
 // ------------------------------------------------------------------ expand + backward + mcts::step
 // mcts.rs:267-288 (expand, backward), then when the rollout count is reached the per-ply part of
 // src/main.rs:198-233: snapshot root/children into the trace, mcts::step (mcts.rs:292-328), outcome.
-__global__ __launch_bounds__(64) void k_expand_backup(SpParams p) {
-    const int g = blockIdx.x, lane = threadIdx.x;
+// value head tail for one position (nn_kernels.hpp k_value_finish, fused here so that the search step needs
+// no separate launch): + meta columns + bias, ReLU, Linear 128->1, tanh, times (2*turn-1)
+__device__ inline float value_from_partials(const SpParams& p, int g, int lane) {
+    const float* wf = p.vf_w;
+    const int32_t* meta = p.meta + (size_t)g * 8;
+    float m[7];
+#pragma unroll
+    for (int k = 0; k < 7; k++) {
+        // meta is fed to the net as bf16 (src/backends/torch.rs:120-123)
+        uint32_t u = __builtin_bit_cast(uint32_t, (float)meta[k]);
+        u = (u + 0x7fffu + ((u >> 16) & 1u)) & 0xffff0000u;
+        m[k] = __builtin_bit_cast(float, u);
+    }
+    float part = 0.f;
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        int j = lane + 64 * h;
+        float acc[32];
+#pragma unroll
+        for (int ks = 0; ks < 32; ks++) acc[ks] = ks < p.vf_ksplit ? p.vpart[((size_t)ks * p.n_slots + g) * 128 + j] : 0.f;
+        float s = wf[p.vf_fc1b + j];
+#pragma unroll
+        for (int ks = 0; ks < 32; ks++) s += acc[ks];
+#pragma unroll
+        for (int k = 0; k < 7; k++) s += m[k] * wf[p.vf_fc1m + k * 128 + j];
+        s = s > 0.f ? s : 0.f;
+        part += s * wf[p.vf_fc2w + j];
+    }
+    part = wave_sum_f(part);
+    float v = tanhf(part + wf[p.vf_fc2b]);
+    return v * (float)(meta[0] * 2 - 1);
+}
+
+__device__ __noinline__ void dev_expand(SpParams& p, int g, int lane, Position* s_np_p) {
+    Position& s_np = *s_np_p;
     GameCtl& c = p.ctl[g];
     if (c.status != ST_ACTIVE || c.leaf_kind == LK_NONE) return;
     const size_t nb = (size_t)g * p.node_cap;
@@ -452,7 +482,7 @@ __global__ __launch_bounds__(64) void k_expand_backup(SpParams p) {
     int n_nodes = c.n_nodes, n_exp = c.n_exp;
     uint32_t err = 0;
     if (kind == LK_EVAL) {
-        value = p.value[g];
+        value = p.vf_fused ? value_from_partials(p, g, lane) : p.value[g];
         int n = c.n_legal;
         if (n_nodes + n > p.node_cap || n_exp + 1 >= p.tpos_cap) {
             err = ERR_POOL_OVERFLOW;
@@ -573,7 +603,6 @@ __global__ __launch_bounds__(64) void k_expand_backup(SpParams p) {
     // advance the game line
     Position np = hist[ply];
     make_move(np, mv);
-    __shared__ Position s_np;
     if (lane == 0) s_np = np;
     __syncthreads();
     {
@@ -621,6 +650,21 @@ __global__ __launch_bounds__(64) void k_expand_backup(SpParams p) {
         c.n_exp = 1;
         c.sim = 0;
     }
+}
+
+// One launch per simulation step: finish the previous simulation of every game (value head tail, expand,
+// backward, and at the end of a ply mcts::step + trace + outcome), then select the next leaf and encode it.
+__global__ __launch_bounds__(64) void k_mcts(SpParams p, int do_expand, int do_select) {
+    const int g = blockIdx.x, lane = threadIdx.x;
+    __shared__ __attribute__((aligned(16))) int8_t s_stage[7168];
+    __shared__ move_t s_moves[MAXC];
+    __shared__ Position s_pos;
+    if (do_expand) {
+        dev_expand(p, g, lane, &s_pos);
+        __threadfence_block();
+        __syncthreads();
+    }
+    if (do_select) dev_select(p, g, lane, s_stage, s_moves, &s_pos);
 }
 
 // ------------------------------------------------------------------ sc_selfplay_set_position

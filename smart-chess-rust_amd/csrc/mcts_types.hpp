@@ -67,6 +67,11 @@ struct SpParams {
     float* t_cq;
     float* t_cu;
     Counters* cnt;
+    // fused value-head tail (NET evaluator): split-K partials of value_head.ffn.0 + fp32 parameters
+    int vf_fused, vf_ksplit;
+    const float* vpart;
+    const float* vf_w;
+    uint32_t vf_fc1b, vf_fc1m, vf_fc2w, vf_fc2b;
 };
 
 

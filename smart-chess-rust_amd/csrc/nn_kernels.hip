@@ -1,6 +1,8 @@
 // nn_kernels.hip -- translation unit of the network kernels.
 #include "nn_kernels.hpp"
 
+#include <stdlib.h>
+
 #include <algorithm>
 
 #include "launchers.hpp"
@@ -12,20 +14,29 @@ size_t tower_lds_bytes(int C) {
     return 100 * cp * 2 + rs + 512 * 4 + 640 * 4 + 8 * 4 + 4 * 64 * 8;
 }
 const char* nn_init() {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scnn::k_tower<256>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scnn::k_tower<256, 4>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)tower_lds_bytes(256));
     if (e != hipSuccess) return hipGetErrorString(e);
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scnn::k_tower<128>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scnn::k_tower<256, 8>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)tower_lds_bytes(256));
+    if (e != hipSuccess) return hipGetErrorString(e);
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scnn::k_tower<128, 4>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)tower_lds_bytes(128));
     if (e != hipSuccess) return hipGetErrorString(e);
     return nullptr;
 }
 void tower(const scnn::TowerArgs& a, hipStream_t s) {
     if (a.n_pos <= 0) return;
-    if (a.net.C == 256)
-        hipLaunchKernelGGL(scnn::k_tower<256>, dim3(a.n_pos), dim3(256), tower_lds_bytes(256), s, a);
+    static const int ring = getenv("SC_TOWER_RING") ? atoi(getenv("SC_TOWER_RING")) : 4;     // experiment knobs
+    static const int stagger = getenv("SC_TOWER_STAGGER") ? atoi(getenv("SC_TOWER_STAGGER")) : 0;
+    scnn::TowerArgs b = a;
+    b.stagger = stagger;
+    if (a.net.C == 256 && ring == 8)
+        hipLaunchKernelGGL((scnn::k_tower<256, 8>), dim3(a.n_pos), dim3(256), tower_lds_bytes(256), s, b);
+    else if (a.net.C == 256)
+        hipLaunchKernelGGL((scnn::k_tower<256, 4>), dim3(a.n_pos), dim3(256), tower_lds_bytes(256), s, b);
     else
-        hipLaunchKernelGGL(scnn::k_tower<128>, dim3(a.n_pos), dim3(256), tower_lds_bytes(128), s, a);
+        hipLaunchKernelGGL((scnn::k_tower<128, 4>), dim3(a.n_pos), dim3(256), tower_lds_bytes(128), s, b);
 }
 void value_fc1(const scnn::Fc1Args& a, hipStream_t s) {
     if (a.n_pos <= 0) return;

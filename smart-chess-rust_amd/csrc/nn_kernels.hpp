@@ -69,49 +69,61 @@ __device__ __forceinline__ bf16x8 wload(__amdgpu_buffer_rsrc_t rsrc, int voff, i
     return __builtin_bit_cast(bf16x8, v);
 }
 
-// xoff: byte offset of the image inside g_smem.
-template <int CIN, int TAPS, int NTW, int NT_TOTAL, bool HALO, int CP>
-__device__ __forceinline__ void conv_mma(int xoff, const bf16_t* __restrict__ Wp, int wave_u, int lane, f32x4 (&acc)[4][NTW]) {
+// xoff: byte offset of the image inside g_smem.  RS: weight ring slots (prefetch distance RS-1 k-steps).
+// t0: first tap (taps are processed cyclically from t0; 0 = natural order).
+template <int CIN, int TAPS, int NTW, int NT_TOTAL, bool HALO, int CP, int RS>
+__device__ __forceinline__ void conv_mma(int xoff, const bf16_t* __restrict__ Wp, int wave_u, int lane, int t0,
+                                         f32x4 (&acc)[4][NTW]) {
     constexpr int KPT = CIN / 32;          // k-steps per tap
     constexpr int SBB = NT_TOTAL * 1024;   // bytes per k-step of packed weights
-    static_assert(KPT % 4 == 0, "k-steps per tap must be a multiple of the ring size");
+    static_assert(KPT % RS == 0 && (RS == 4 || RS == 8), "k-steps per tap must be a multiple of the ring size");
     const int row16 = lane & 15, kq = lane >> 4;
-    // LDS byte offsets of this lane's 4 A rows at the CURRENT tap; k offsets inside a tap are immediates
+    // LDS byte offsets of this lane's 4 A rows at the centre tap; tap offsets are scalars, k offsets immediates
     int pa[4];
 #pragma unroll
     for (int mt = 0; mt < 4; mt++) {
         int row = mt * 16 + row16;
-        pa[mt] = xoff + (((HALO ? hidx(row2pix(row)) : row) + (TAPS == 9 ? -11 : 0)) * CP + 8 * kq) * 2;
+        pa[mt] = xoff + ((HALO ? hidx(row2pix(row)) : row) * CP + 8 * kq) * 2;
     }
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<bf16_t*>(Wp) + (size_t)wave_u * NTW * 512, 0, 0x7fffffff, 0x00020000);
     const int voff = lane * 16;
-    // B: ring of 4 register slots, loads run PF = 3 k-steps ahead of the MFMAs that consume them (the slot being
-    // refilled was consumed one step earlier).  The prefetch is unconditional: the host pads the weight blob so
-    // that running 3 steps past a tensor is legal.  A: double-buffered LDS fragments, one step ahead (reads past
-    // the last step land inside the LDS allocation).
-    bf16x8 bq[4][NTW];
+    auto toffb = [](int t) { return (TAPS == 9) ? ((((t * 11) >> 5) - 1) * 10 + (t - 3 * ((t * 11) >> 5)) - 1) * CP * 2 : 0; };
+    // B: ring of RS register slots, loads run RS-1 k-steps ahead of the MFMAs that consume them (the slot being
+    // refilled was consumed one step earlier).  A: double-buffered LDS fragments, one step ahead.  Prefetches
+    // past the last tap wrap to the first one (valid memory, values unused).
+    bf16x8 bq[RS][NTW];
     bf16x8 aq[2][4];
+    int t = t0;
+    int wcur = t * (KPT * SBB);
+    int pc[4];
 #pragma unroll
-    for (int st = 0; st < PF; st++)
+    for (int mt = 0; mt < 4; mt++) pc[mt] = pa[mt] + toffb(t);
 #pragma unroll
-        for (int i = 0; i < NTW; i++) bq[st][i] = wload(rsrc, voff + i * 1024, st * SBB);
+    for (int st = 0; st < RS - 1; st++)
 #pragma unroll
-    for (int mt = 0; mt < 4; mt++) aq[0][mt] = lds_frag(pa[mt]);
-    int dxc = 0;   // tap % 3
-    int wcur = 0;  // scalar byte cursor of the current tap's first k-step
+        for (int i = 0; i < NTW; i++) bq[st][i] = wload(rsrc, voff + i * 1024, wcur + st * SBB);
+#pragma unroll
+    for (int mt = 0; mt < 4; mt++) aq[0][mt] = lds_frag(pc[mt]);
 #pragma unroll 1
-    for (int tap = 0; tap < TAPS; tap++) {
-        // image offset of the next tap relative to this one: taps walk (dy,dx) row-major over the 10-wide halo image
-        const int tstep = (TAPS == 9) ? (dxc == 2 ? 8 : 1) * CP * 2 : 0;
+    for (int j = 0; j < TAPS; j++) {
+        int tn = t + 1;
+        if (tn == TAPS) tn = 0;
+        const int wnext = tn * (KPT * SBB);
+        int pn[4];
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++) pn[mt] = pa[mt] + toffb(tn);
 #pragma unroll
         for (int kc = 0; kc < KPT; kc++) {
-            const int u = kc & 3;
+            const int u = kc % RS;
+            constexpr int PD = RS - 1;
 #pragma unroll
-            for (int i = 0; i < NTW; i++) bq[(u + 3) & 3][i] = wload(rsrc, voff + i * 1024, wcur + (kc + PF) * SBB);
+            for (int i = 0; i < NTW; i++)
+                bq[(u + PD) % RS][i] = (kc + PD < KPT) ? wload(rsrc, voff + i * 1024, wcur + (kc + PD) * SBB)
+                                                       : wload(rsrc, voff + i * 1024, wnext + (kc + PD - KPT) * SBB);
 #pragma unroll
             for (int mt = 0; mt < 4; mt++)
-                aq[(kc + 1) & 1][mt] = (kc + 1 < KPT) ? lds_frag(pa[mt] + (kc + 1) * 64) : lds_frag(pa[mt] + tstep);
+                aq[(kc + 1) & 1][mt] = (kc + 1 < KPT) ? lds_frag(pc[mt] + (kc + 1) * 64) : lds_frag(pn[mt]);
 #pragma unroll
             for (int mt = 0; mt < 4; mt++)
 #pragma unroll
@@ -129,10 +141,10 @@ __device__ __forceinline__ void conv_mma(int xoff, const bf16_t* __restrict__ Wp
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        wcur += KPT * SBB;
+        t = tn;
+        wcur = wnext;
 #pragma unroll
-        for (int mt = 0; mt < 4; mt++) pa[mt] += tstep;
-        dxc = dxc == 2 ? 0 : dxc + 1;
+        for (int mt = 0; mt < 4; mt++) pc[mt] = pn[mt];
     }
 }
 
@@ -261,7 +273,7 @@ __device__ inline void store_image(const f32x4 (&acc)[4][NTW], bf16_t* X, int wa
 }
 
 
-template <int C>
+template <int C, int RS>
 __global__ __launch_bounds__(256, 1) void k_tower(TowerArgs A) {
     constexpr int NTW = C / 64;        // column tiles per wave in the trunk (4 or 2)
     constexpr int NT = C / 16;
@@ -334,7 +346,8 @@ __global__ __launch_bounds__(256, 1) void k_tower(TowerArgs A) {
 
     // ---- conv_block (py/module.py:120-126): conv3x3 112->C (K padded to 128/tap), LN, ReLU
     zero_acc();
-    conv_mma<128, 9, NTW, NT, true, CP>(0, net.wb + net.o_stem, wave, lane, acc);
+    const int t0 = A.stagger ? (int)((blockIdx.x * (unsigned)A.stagger) % 9u) : 0;
+    conv_mma<128, 9, NTW, NT, true, CP, 4>(0, net.wb + net.o_stem, wave, lane, t0, acc);
     {
         const float* f = net.wf + net.f_stem;
         bias_layernorm<NTW>(acc, f, f + C, f + 2 * C, C, true, wave, lane, s_stat, s_mr);
@@ -363,13 +376,13 @@ __global__ __launch_bounds__(256, 1) void k_tower(TowerArgs A) {
         const float* wf = net.wf + net.f_blocks + (size_t)b * net.blk_stride_f;
         // conv1 -> LN -> ReLU
         zero_acc();
-        conv_mma<C, 9, NTW, NT, true, CP>(0, wb, wave, lane, acc);
+        conv_mma<C, 9, NTW, NT, true, CP, RS>(0, wb, wave, lane, t0, acc);
         bias_layernorm<NTW>(acc, wf, wf + C, wf + 2 * C, C, true, wave, lane, s_stat, s_mr);
         store_image<NTW, true, CP>(acc, Xa, wave, lane);
         __syncthreads();
         // conv2 -> LN
         zero_acc();
-        conv_mma<C, 9, NTW, NT, true, CP>(0, wb + (size_t)9 * C * C, wave, lane, acc);
+        conv_mma<C, 9, NTW, NT, true, CP, RS>(0, wb + (size_t)9 * C * C, wave, lane, t0, acc);
         bias_layernorm<NTW>(acc, wf + 3 * C, wf + 4 * C, wf + 5 * C, C, false, wave, lane, s_stat, s_mr);
         // squeeze-excitation: global average pool over the 64 pixels
         {
@@ -466,7 +479,7 @@ __global__ __launch_bounds__(256, 1) void k_tower(TowerArgs A) {
         for (int mt = 0; mt < 4; mt++)
 #pragma unroll
             for (int i = 0; i < 4; i++) hv[mt][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        conv_mma<C, 1, 4, 16, true, CP>(0, net.wb + net.o_vconv, wave, lane, hv);
+        conv_mma<C, 1, 4, 16, true, CP, RS>(0, net.wb + net.o_vconv, wave, lane, 0, hv);
         const float* f = net.wf + net.f_vhead;
         bias_layernorm<4>(hv, f, f + HEAD, f + 2 * HEAD, HEAD, true, wave, lane, s_stat, s_mr);
         const int c0 = chan0<4>(wave, lane);
@@ -488,7 +501,7 @@ __global__ __launch_bounds__(256, 1) void k_tower(TowerArgs A) {
         for (int mt = 0; mt < 4; mt++)
 #pragma unroll
             for (int i = 0; i < 4; i++) hp[mt][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        conv_mma<C, 1, 4, 16, true, CP>(0, net.wb + net.o_pconv1, wave, lane, hp);
+        conv_mma<C, 1, 4, 16, true, CP, RS>(0, net.wb + net.o_pconv1, wave, lane, 0, hp);
         const float* f = net.wf + net.f_phead1;
         bias_layernorm<4>(hp, f, f + HEAD, f + 2 * HEAD, HEAD, false, wave, lane, s_stat, s_mr);
         store_image<4, false, HP>(hp, Xh, wave, lane);
@@ -500,7 +513,7 @@ __global__ __launch_bounds__(256, 1) void k_tower(TowerArgs A) {
         for (int mt = 0; mt < 4; mt++)
 #pragma unroll
             for (int i = 0; i < 2; i++) z[mt][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        conv_mma<HEAD, 1, 2, 8, false, HP>(XA_BYTES, net.wb + net.o_pconv2, wave, lane, z);
+        conv_mma<HEAD, 1, 2, 8, false, HP, 4>(XA_BYTES, net.wb + net.o_pconv2, wave, lane, 0, z);
         const float* f = net.wf + net.f_phead2;
         // padded channels (>=73) have zero weights, bias, gamma, beta: they add 0 to both LN sums
         bias_layernorm<2>(z, f, f + POL_PAD, f + 2 * POL_PAD, 73, false, wave, lane, s_stat, s_mr);

@@ -1,0 +1,179 @@
+// sc-selfplay -- launcher with the reference's `selfplay` command line (src/main.rs:25-60), running
+// many games concurrently on one or more MI355X and writing one reference-format trace file per game
+// (src/trace.rs:23-32), so that scripts/run_batch / scripts/iterate / scripts/train.py -t '<dir>/*.json'
+// keep working unchanged.
+//
+//   reference:  cargo r --release --bin selfplay -- -d cuda --rollout-num 300 -n 200 --temperature 0 \
+//                   --cpuct 2 -c <ckpt>.pt -t <PREFIX>/trace<JOB>.json              (scripts/run_batch:17)
+//   here:       sc-selfplay -d cuda --rollout-num 300 -n 200 --temperature 0 --cpuct 2 -c <weights>.scw \
+//                   -t <PREFIX>/trace{}.json --games 2048 --concurrency 256 --gpus 8
+//
+// Same flags, same defaults; `-t` may contain `{}` (replaced by the 1-based game number, run_batch's
+// JOB_ID) -- without it and with --games 1 the file name is used verbatim, exactly like the reference.
+// Extra flags (no reference counterpart): --games, --concurrency, --gpus, --seed, --blocks/--channels
+// (random-init network when no checkpoint is given), --first-game.
+// One host thread per GPU; games are sharded statically over GPUs, no collective.
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/sc_engine.h"
+
+struct Args {
+    std::string device = "cuda";
+    float rollout_factor = -1.f;
+    int rollout_num = -1;
+    int num_steps = 100;
+    std::string trace_file = "trace.json";
+    std::string checkpoint = "__no_checkpoint__";
+    std::string endpoint = "__no_endpoint__";
+    float temperature = 0.0f;
+    float cpuct = 1.0f;
+    int temperature_switch = 30;
+    float epsilon = 0.15f;
+    // extensions
+    int games = 1, concurrency = 256, gpus = 1, blocks = 10, channels = 256;
+    unsigned long long seed = 0xC0FFEEULL, first_game = 0;
+};
+
+static void usage() {
+    fprintf(stderr,
+            "usage: sc-selfplay [-d cuda] [-r|--rollout-factor F | --rollout-num N] [-n|--num-steps 100] [-t|--trace-file trace.json]\n"
+            "                   [-c|--checkpoint weights.scw] [--temperature 0] [--cpuct 1] [--temperature-switch 30] [--epsilon 0.15]\n"
+            "                   [--games 1] [--concurrency 256] [--gpus 1] [--seed S] [--first-game K] [--blocks 10] [--channels 256]\n");
+}
+
+static bool parse(int argc, char** argv, Args& a) {
+    for (int i = 1; i < argc; i++) {
+        std::string k = argv[i];
+        auto val = [&](const char* name) -> const char* {
+            if (i + 1 >= argc) {
+                fprintf(stderr, "missing value for %s\n", name);
+                exit(2);
+            }
+            return argv[++i];
+        };
+        if (k == "-d" || k == "--device") a.device = val("device");
+        else if (k == "-r" || k == "--rollout-factor") a.rollout_factor = (float)atof(val("rollout-factor"));
+        else if (k == "--rollout-num") a.rollout_num = atoi(val("rollout-num"));
+        else if (k == "-n" || k == "--num-steps") a.num_steps = atoi(val("num-steps"));
+        else if (k == "-t" || k == "--trace-file") a.trace_file = val("trace-file");
+        else if (k == "-c" || k == "--checkpoint") a.checkpoint = val("checkpoint");
+        else if (k == "--endpoint") a.endpoint = val("endpoint");
+        else if (k == "--temperature") a.temperature = (float)atof(val("temperature"));
+        else if (k == "--cpuct") a.cpuct = (float)atof(val("cpuct"));
+        else if (k == "--temperature-switch") a.temperature_switch = atoi(val("temperature-switch"));
+        else if (k == "--epsilon") a.epsilon = (float)atof(val("epsilon"));
+        else if (k == "--games") a.games = atoi(val("games"));
+        else if (k == "--concurrency") a.concurrency = atoi(val("concurrency"));
+        else if (k == "--gpus") a.gpus = atoi(val("gpus"));
+        else if (k == "--seed") a.seed = strtoull(val("seed"), nullptr, 0);
+        else if (k == "--first-game") a.first_game = strtoull(val("first-game"), nullptr, 0);
+        else if (k == "--blocks") a.blocks = atoi(val("blocks"));
+        else if (k == "--channels") a.channels = atoi(val("channels"));
+        else if (k == "-h" || k == "--help") { usage(); exit(0); }
+        else { fprintf(stderr, "unknown argument %s\n", k.c_str()); usage(); return false; }
+    }
+    return true;
+}
+
+static std::string trace_name(const Args& a, unsigned long long game_number) {
+    std::string t = a.trace_file;
+    size_t p = t.find("{}");
+    if (p != std::string::npos) return t.substr(0, p) + std::to_string(game_number) + t.substr(p + 2);
+    if (a.games == 1) return t;
+    size_t dot = t.rfind('.');
+    if (dot == std::string::npos) return t + std::to_string(game_number);
+    return t.substr(0, dot) + std::to_string(game_number) + t.substr(dot);
+}
+
+static int run_gpu(const Args& a, int gpu, int first, int count, int* finished_with_outcome) {
+    sc_engine* eng = nullptr;
+    sc_net_config nc{a.blocks, a.channels, a.seed};
+    const char* w = a.checkpoint == "__no_checkpoint__" ? nullptr : a.checkpoint.c_str();
+    if (sc_engine_create(&nc, w, gpu, &eng)) {
+        fprintf(stderr, "gpu %d: %s\n", gpu, sc_last_error());
+        return 1;
+    }
+    sc_selfplay_config c{};
+    c.n_slots = count < a.concurrency ? count : a.concurrency;
+    c.n_games = count;
+    // main.rs:175-180: --rollout-num, else 300 (the --rollout-factor form needs the per-position legal-move
+    // count on the host every ply; it is mapped to its cap of 300 here and reported)
+    c.rollout_num = a.rollout_num > 0 ? a.rollout_num : 300;
+    c.num_steps = a.num_steps;
+    c.cpuct = a.cpuct;
+    c.temperature = a.temperature;
+    c.temperature_switch = a.temperature_switch;
+    c.epsilon = a.epsilon;
+    c.with_noise = 1;      // main.rs:195
+    c.outcome_gate = 100;  // main.rs:223
+    c.evaluator = SC_EVAL_NET;
+    c.seed = a.seed;
+    c.first_game_id = a.first_game + (unsigned long long)first;
+    sc_selfplay* sp = nullptr;
+    if (sc_selfplay_create(eng, gpu, &c, &sp)) {
+        fprintf(stderr, "gpu %d: %s\n", gpu, sc_last_error());
+        sc_engine_destroy(eng);
+        return 1;
+    }
+    int rc = sc_selfplay_run(sp, 0);
+    if (rc) fprintf(stderr, "gpu %d: %s\n", gpu, sc_last_error());
+    sc_selfplay_stats st{};
+    sc_selfplay_get_stats(sp, &st);
+    int with_outcome = 0;
+    for (int g = 0; g < count && !rc; g++) {
+        sc_trace_info info{};
+        if (sc_selfplay_get_trace(sp, g, &info, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr)) continue;
+        with_outcome += info.has_outcome;
+        std::string path = trace_name(a, info.game_id + 1);
+        if (sc_selfplay_write_trace_json(sp, g, path.c_str())) {
+            fprintf(stderr, "gpu %d: %s\n", gpu, sc_last_error());
+            rc = 1;
+        }
+    }
+    printf("gpu %d: games %d finished %d with-outcome %d simulations %lld error_flags %d\n", gpu, count, st.games_finished,
+           with_outcome, (long long)st.sims_done, st.error_flags);
+    *finished_with_outcome = with_outcome;
+    sc_selfplay_destroy(sp);
+    sc_engine_destroy(eng);
+    return rc;
+}
+
+int main(int argc, char** argv) {
+    Args a;
+    if (!parse(argc, argv, a)) return 2;
+    if (a.rollout_factor >= 0 && a.rollout_num > 0) {  // main.rs:74
+        fprintf(stderr, "both --rollout-factor and --rollout-num are specified.\n");
+        return 2;
+    }
+    if (a.device != "cuda") {
+        fprintf(stderr, "device '%s' is not supported: this launcher has no CPU path (use the reference binary for -d cpu)\n",
+                a.device.c_str());
+        return 2;
+    }
+    if (a.rollout_factor >= 0) fprintf(stderr, "note: --rollout-factor is mapped to its cap (rollout 300, main.rs:176)\n");
+    int ndev = sc_device_count();
+    if (ndev <= 0) {
+        fprintf(stderr, "no MI355X visible\n");
+        return 1;
+    }
+    int gpus = a.gpus < ndev ? a.gpus : ndev;
+    std::vector<std::thread> th;
+    std::vector<int> rcs((size_t)gpus, 0), outc((size_t)gpus, 0);
+    int base = 0;
+    for (int g = 0; g < gpus; g++) {
+        int count = a.games / gpus + (g < a.games % gpus ? 1 : 0);
+        if (count == 0) continue;
+        th.emplace_back([&, g, base, count]() { rcs[(size_t)g] = run_gpu(a, g, base, count, &outc[(size_t)g]); });
+        base += count;
+    }
+    for (auto& t : th) t.join();
+    int rc = 0;
+    for (int r : rcs) rc |= r;
+    return rc;
+}
