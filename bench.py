@@ -105,30 +105,50 @@ def run_gpu(args, rank, world, local_rank):
     res = {}
     for tag, C in (("main", args.channels),) + ((("alt", 256 if args.channels == 128 else 128),) if args.alt and world == 1 else ()):
         eng = scamd.Engine(args.blocks, C, seed=1, device=local_rank)
-        sp = scamd.SelfPlay(eng, n_slots=G, n_games=10 ** 7, trace_capacity=4 * G, rollout_num=R, num_steps=150, cpuct=2.5,
-                            temperature=0.0, temperature_switch=4, epsilon=0.15, with_noise=True, seed=1234,
-                            first_game_id=shard(10 ** 7, rank), device=local_rank)
+        K = max(1, args.groups)
+        assert G % K == 0
+        sps = [scamd.SelfPlay(eng, n_slots=G // K, n_games=10 ** 7 // K, trace_capacity=4 * G // K, rollout_num=R, num_steps=150,
+                              cpuct=2.5, temperature=0.0, temperature_switch=4, epsilon=0.15, with_noise=True, seed=1234,
+                              first_game_id=shard(10 ** 7, rank) + k * (10 ** 7 // K), own_stream=K > 1, device=local_rank)
+               for k in range(K)]
+
+        def enqueue(n):
+            if K == 1:
+                sps[0].enqueue(n)
+            else:
+                scamd.enqueue_interleaved(sps, n)
+
+        def stats():
+            tot = {}
+            for sp in sps:
+                for k, v in sp.stats().items():
+                    tot[k] = tot.get(k, 0) + v if k != "error_flags" else tot.get(k, 0) | v
+            return tot
+
         steps = args.steps if tag == "main" else max(2, args.steps // 4)
-        sp.enqueue(args.warmup * R)
-        sp.sync()
-        s0 = sp.stats()
-        sp.enable_timing(args.timing_stride)
-        sp.timing(reset=True)
+        enqueue(args.warmup * R)
+        s0 = stats()
+        for sp in sps:
+            sp.enable_timing(args.timing_stride)
+            sp.timing(reset=True)
         barrier()
         t0 = time.perf_counter()
         for _ in range(steps):
-            sp.enqueue(R)
-        sp.sync()
+            enqueue(R)
+        for sp in sps:
+            sp.sync()
         cuda_sync()
         t1 = time.perf_counter()
         barrier()
-        tm = sp.timing()
-        s1 = sp.stats()
+        tms = [sp.timing() for sp in sps]
+        s1 = stats()
+        nl = sum(t["tower_launches"] for t in tms)
         res[tag] = dict(C=C, seconds=t1 - t0, steps=steps, sims=s1["sims_done"] - s0["sims_done"],
                         nn_evals=s1["nn_evals"] - s0["nn_evals"], err=s1["error_flags"],
-                        tower_ms=tm["ms_tower_sum"] / max(tm["tower_launches"], 1), tower_launches=tm["tower_launches"],
-                        span_ms=tm["ms_total"])
-        sp.close()
+                        tower_ms=sum(t["ms_tower_sum"] for t in tms) / max(nl, 1), tower_launches=nl,
+                        span_ms=max(t["ms_total"] for t in tms), groups=K)
+        for sp in sps:
+            sp.close()
         eng.close()
     return res
 
@@ -161,6 +181,7 @@ def main():
     ap.add_argument("--blocks", type=int, default=10)
     ap.add_argument("--channels", type=int, default=128, help="trunk width: 128 = BASELINE configs[1]; 256 = reference module")
     ap.add_argument("--no-alt", dest="alt", action="store_false", help="skip the short run of the other trunk width")
+    ap.add_argument("--groups", type=int, default=1, help="split the games of a GPU into K groups on K HIP streams (overlap)")
     ap.add_argument("--timing-stride", type=int, default=1)
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU work for cpu_baseline (0 = skip)")
     ap.add_argument("--cpu-dry-run", action="store_true",
@@ -237,12 +258,13 @@ def main():
             },
         }
         if not args.cpu_dry_run:
-            tf = args.games * flop_pos / (m["tower_ms"] * 1e-3) / 1e12 if m["tower_ms"] > 0 else 0.0
+            pos_per_launch = args.games // m.get("groups", 1)
+            tf = pos_per_launch * flop_pos / (m["tower_ms"] * 1e-3) / 1e12 if m["tower_ms"] > 0 else 0.0
             out["roofline"] = {
                 "bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(tf / PEAK_BF16_TFLOPS, 4), "traffic": load_traffic(m["C"]),
                 "kernel": f"k_tower<{m['C']}>", "avg_launch_ms": round(m["tower_ms"], 4), "launches_timed": m["tower_launches"],
-                "flop_per_launch": args.games * flop_pos,
+                "flop_per_launch": pos_per_launch * flop_pos, "positions_per_launch": pos_per_launch, "concurrent_groups": m.get("groups", 1),
                 "end_to_end_frac": round(sims / seconds / world * flop_pos / (PEAK_BF16_TFLOPS * 1e12), 4),
             }
             out["nn_evals_per_sim"] = round(m["nn_evals"] / max(m["sims"], 1), 4)

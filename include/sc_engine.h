@@ -109,7 +109,8 @@ typedef struct {
     uint64_t first_game_id;     /* global id of this handle's first game (sharding across GPUs/ranks) */
     int32_t trace_capacity;     /* traces kept on the device: 0 = n_games (every trace retrievable); >0 = ring of that
                                    many games (>= 2*n_slots), older traces are overwritten (throughput runs) */
-    int32_t reserved;
+    int32_t own_stream;         /* 1: this handle launches on its own HIP stream, so several handles (groups of games)
+                                   of one engine overlap on the GPU: one group's tree work hides under another's network */
 } sc_selfplay_config;
 
 int sc_selfplay_create(sc_engine* engine_or_null, int device_id, const sc_selfplay_config* cfg, sc_selfplay** out);
@@ -119,6 +120,9 @@ void sc_selfplay_destroy(sc_selfplay*);
  * game, including the per-ply move choice of mcts::step when a game's rollout count is reached). */
 int sc_selfplay_enqueue_sims(sc_selfplay*, int n);
 int sc_selfplay_synchronize(sc_selfplay*);
+/* Enqueue n simulation steps on several handles of one GPU, interleaved step by step (handles created with
+ * own_stream = 1 overlap on the device). */
+int sc_selfplay_enqueue_interleaved(sc_selfplay** handles, int n_handles, int n);
 /* Run until every game has finished (or max_sim_steps > 0 is reached). */
 int sc_selfplay_run(sc_selfplay*, int64_t max_sim_steps);
 

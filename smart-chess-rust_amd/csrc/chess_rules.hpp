@@ -138,11 +138,24 @@ SC_HD bb_t between(int a, int b) {
     return span & line_through(a, b);
 }
 
+// NOTE: Position members are only ever indexed with compile-time constants (or through the helpers below):
+// a runtime index would pin the struct in scratch memory on the GPU instead of registers.
 SC_HD int piece_type_at(const Position& p, int sq) {
     bb_t b = bit(sq);
-    for (int t = 0; t < 6; t++)
-        if (p.pcs[t] & b) return t;
-    return -1;
+    int r = -1;
+#pragma unroll
+    for (int t = 5; t >= 0; t--)
+        if (p.pcs[t] & b) r = t;
+    return r;
+}
+SC_HD bb_t occ_c(const Position& p, int color) { return color ? p.occ[1] : p.occ[0]; }
+SC_HD void xor_occ(Position& p, int color, bb_t b) {
+    p.occ[0] ^= color ? 0 : b;
+    p.occ[1] ^= color ? b : 0;
+}
+SC_HD void xor_pcs(Position& p, int type, bb_t b) {
+#pragma unroll
+    for (int t = 0; t < 6; t++) p.pcs[t] ^= (t == type) ? b : 0;
 }
 SC_HD bb_t all_occ(const Position& p) { return p.occ[0] | p.occ[1]; }
 
@@ -151,7 +164,7 @@ SC_HD bb_t attackers_mask(const Position& p, int color, int sq, bb_t occ) {
     bb_t rq = p.pcs[ROOK] | p.pcs[QUEEN], bq = p.pcs[BISHOP] | p.pcs[QUEEN];
     bb_t a = (rook_attacks(sq, occ) & rq) | (bishop_attacks(sq, occ) & bq) | (knight_attacks_bb(bit(sq)) & p.pcs[KNIGHT]) |
              (king_attacks_bb(bit(sq)) & p.pcs[KING]) | (pawn_attacks_bb(!color, bit(sq)) & p.pcs[PAWN]);
-    return a & p.occ[color] & occ;
+    return a & occ_c(p, color) & occ;
 }
 SC_HD bb_t piece_attacks(const Position& /*p*/, int sq, int type, int color, bb_t occ) {
     switch (type) {
@@ -188,17 +201,17 @@ SC_HD bb_t ep_capturers(const Position& p, bb_t from_mask) {
     if (p.ep < 0) return 0;
     int us = p.turn;
     bb_t rank = us ? (RANK_1 << 32) : (RANK_1 << 24);
-    return p.pcs[PAWN] & p.occ[us] & from_mask & pawn_attacks_bb(!us, bit(p.ep)) & rank;
+    return p.pcs[PAWN] & occ_c(p, us) & from_mask & pawn_attacks_bb(!us, bit(p.ep)) & rank;
 }
 // exact: play the capture on the bitboards and look for attackers of our king
 SC_HD bool ep_is_legal(const Position& p, int from) {
     int us = p.turn;
-    bb_t kbb = p.pcs[KING] & p.occ[us];
+    bb_t kbb = p.pcs[KING] & occ_c(p, us);
     if (!kbb) return true;
     int king = msb(kbb);
     int capsq = p.ep + (us ? -8 : 8);
     bb_t occ = (all_occ(p) ^ bit(from) ^ bit(capsq)) | bit(p.ep);
-    bb_t theirs = p.occ[!us] & ~bit(capsq);
+    bb_t theirs = occ_c(p, !us) & ~bit(capsq);
     bb_t rq = (p.pcs[ROOK] | p.pcs[QUEEN]) & theirs, bq = (p.pcs[BISHOP] | p.pcs[QUEEN]) & theirs;
     bb_t a = (rook_attacks(king, occ) & rq) | (bishop_attacks(king, occ) & bq) | (knight_attacks_bb(kbb) & p.pcs[KNIGHT] & theirs) |
              (pawn_attacks_bb(us, kbb) & p.pcs[PAWN] & theirs) | (king_attacks_bb(kbb) & p.pcs[KING] & theirs);
@@ -215,27 +228,30 @@ SC_HD bool has_legal_ep(const Position& p) {
     return false;
 }
 
-// hash of _transposition_key(): pieces, turn, clean castling rights, ep square iff a legal ep exists
+// hash of _transposition_key(): pieces, turn, clean castling rights, ep square iff a legal ep exists.
+// Zobrist-style: XOR of per-(piece,square) keys and one state key, so make_move can update it incrementally.
+SC_HD bb_t psq_key(int type, int is_white, int sq) { return mix64(((uint64_t)(type + (is_white ? 0 : 6)) << 8) | (uint64_t)sq); }
+SC_HD bb_t state_key(int turn, int castling, int ep_if_legal) {
+    return mix64(0x10000ULL | (uint64_t)turn | ((uint64_t)castling << 1) | ((uint64_t)(ep_if_legal + 1) << 5));
+}
 SC_HD bb_t position_key(const Position& p) {
     bb_t h = 0;
+#pragma unroll
     for (int t = 0; t < 6; t++) {
         bb_t b = p.pcs[t];
         while (b) {
             int sq = lsb(b);
             b &= b - 1;
-            int code = t + ((p.occ[WHITE] >> sq) & 1 ? 0 : 6);
-            h ^= mix64(((uint64_t)code << 8) | (uint64_t)sq);
+            h ^= psq_key(t, (int)((p.occ[WHITE] >> sq) & 1), sq);
         }
     }
-    int ep = has_legal_ep(p) ? p.ep : -1;
-    h ^= mix64(0x10000ULL | (uint64_t)p.turn | ((uint64_t)p.castling << 1) | ((uint64_t)(ep + 1) << 5));
-    return h;
+    return h ^ state_key(p.turn, p.castling, has_legal_ep(p) ? p.ep : -1);
 }
 
 // ------------------------------------------------------------------ Board.push
 SC_HD bool is_zeroing(const Position& p, move_t m) {
     bb_t touched = bit(mv_from(m)) ^ bit(mv_to(m));
-    return (touched & p.pcs[PAWN]) || (touched & p.occ[!p.turn]);
+    return (touched & p.pcs[PAWN]) || (touched & occ_c(p, !p.turn));
 }
 SC_HD uint8_t castle_bit_for_sq(int sq) { return sq == 7 ? 1 : sq == 0 ? 2 : sq == 63 ? 4 : sq == 56 ? 8 : 0; }
 SC_HD bool reduces_castling(const Position& p, move_t m) {
@@ -249,36 +265,43 @@ SC_HD bool reduces_castling(const Position& p, move_t m) {
 // python-chess is_irreversible(move), evaluated on the position BEFORE the move
 SC_HD bool is_irreversible(const Position& p, move_t m) { return is_zeroing(p, m) || reduces_castling(p, m) || has_legal_ep(p); }
 
-// Plays m on p (flags' REP bits are cleared; IRREV and key are set). Pure function of (p, m).
+// Plays m on p (flags' REP bits are cleared; IRREV and key are set). Pure function of (p, m); p.key must be
+// valid on entry (it is updated incrementally: <= 7 key terms instead of a 32-piece recompute).
 SC_HD void make_move(Position& p, move_t m) {
     int from = mv_from(m), to = mv_to(m), promo = mv_promo(m);
     int us = p.turn, them = !us;
-    bool irrev = is_irreversible(p, m);
+    bool old_ep_legal = has_legal_ep(p);
     bool zero = is_zeroing(p, m);
+    bool irrev = zero || reduces_castling(p, m) || old_ep_legal;  // python-chess is_irreversible
+    bb_t key = p.key ^ state_key(us, p.castling, old_ep_legal ? p.ep : -1);
     int old_ep = p.ep;
     p.ep = -1;
     p.halfmove = zero ? 0 : (uint16_t)(p.halfmove + 1);
     if (us == BLACK) p.fullmove++;
     bb_t fb = bit(from), tb = bit(to);
     int pt = piece_type_at(p, from);
-    int cap = (p.occ[them] & tb) ? piece_type_at(p, to) : -1;
+    int cap = (occ_c(p, them) & tb) ? piece_type_at(p, to) : -1;
     // remove mover
-    p.pcs[pt] ^= fb;
-    p.occ[us] ^= fb;
+    xor_pcs(p, pt, fb);
+    xor_occ(p, us, fb);
+    key ^= psq_key(pt, us, from);
     p.castling &= (uint8_t)~(castle_bit_for_sq(from) | castle_bit_for_sq(to));
     if (pt == KING) p.castling &= us ? (uint8_t)~3 : (uint8_t)~12;
     if (cap >= 0) {
-        p.pcs[cap] ^= tb;
-        p.occ[them] ^= tb;
+        xor_pcs(p, cap, tb);
+        xor_occ(p, them, tb);
+        key ^= psq_key(cap, them, to);
     }
     if (pt == PAWN) {
         int diff = to - from;
         if (diff == 16 && (from >> 3) == 1) p.ep = (int8_t)(from + 8);
         else if (diff == -16 && (from >> 3) == 6) p.ep = (int8_t)(from - 8);
         else if (to == old_ep && (diff == 7 || diff == 9 || diff == -7 || diff == -9) && cap < 0) {
-            bb_t cb = bit(old_ep + (us ? -8 : 8));
+            int csq = old_ep + (us ? -8 : 8);
+            bb_t cb = bit(csq);
             p.pcs[PAWN] ^= cb;
-            p.occ[them] ^= cb;
+            xor_occ(p, them, cb);
+            key ^= psq_key(PAWN, them, csq);
         }
     }
     int placed = pt;
@@ -286,16 +309,18 @@ SC_HD void make_move(Position& p, move_t m) {
     if (pt == KING && (to - from == 2 || from - to == 2)) {
         // castling (stored as the king's two-square move, e.g. e1g1)
         int base = from & 56;
-        bb_t rf = to > from ? bit(base + 7) : bit(base + 0);
-        bb_t rt = to > from ? bit(base + 5) : bit(base + 3);
+        int rfs = to > from ? base + 7 : base + 0, rts = to > from ? base + 5 : base + 3;
+        bb_t rf = bit(rfs), rt = bit(rts);
         p.pcs[ROOK] ^= rf | rt;
-        p.occ[us] ^= rf | rt;
+        xor_occ(p, us, rf | rt);
+        key ^= psq_key(ROOK, us, rfs) ^ psq_key(ROOK, us, rts);
     }
-    p.pcs[placed] |= tb;
-    p.occ[us] |= tb;
+    xor_pcs(p, placed, tb);  // the target square is empty at this point (a captured piece was removed above)
+    xor_occ(p, us, tb);
+    key ^= psq_key(placed, us, to);
     p.turn = (uint8_t)them;
     p.flags = irrev ? F_IRREV : 0;
-    p.key = position_key(p);
+    p.key = key ^ state_key(them, p.castling, has_legal_ep(p) ? p.ep : -1);
 }
 
 // ------------------------------------------------------------------ legal move generation
@@ -303,7 +328,7 @@ SC_HD void make_move(Position& p, move_t m) {
 SC_HD bb_t slider_blockers(const Position& p, int king) {
     int us = p.turn;
     bb_t rq = p.pcs[ROOK] | p.pcs[QUEEN], bq = p.pcs[BISHOP] | p.pcs[QUEEN];
-    bb_t snipers = ((rook_attacks(king, 0) & rq) | (bishop_attacks(king, 0) & bq)) & p.occ[!us];
+    bb_t snipers = ((rook_attacks(king, 0) & rq) | (bishop_attacks(king, 0) & bq)) & occ_c(p, !us);
     bb_t occ = all_occ(p), blockers = 0;
     while (snipers) {
         int s = msb(snipers);
@@ -311,7 +336,7 @@ SC_HD bb_t slider_blockers(const Position& p, int king) {
         bb_t b = between(king, s) & occ;
         if (b && (b & (b - 1)) == 0) blockers |= b;
     }
-    return blockers & p.occ[us];
+    return blockers & occ_c(p, us);
 }
 
 // caller-provided storage (LDS on the device, a local array on the host), capacity MAX_MOVES
@@ -320,30 +345,50 @@ struct MoveList {
     int n;
 };
 
+// squares attacked by `color` when our king is lifted off the board (sliders x-ray through it): the exact
+// "king may not go there" set, also used for the castling path tests (python-chess _attacked_for_king)
+SC_HD bb_t danger_map(const Position& p, int color, bb_t occ_no_king) {
+    bb_t them = occ_c(p, color);
+    bb_t d = pawn_attacks_bb(color, p.pcs[PAWN] & them) | knight_attacks_bb(p.pcs[KNIGHT] & them) | king_attacks_bb(p.pcs[KING] & them);
+    bb_t diag = (p.pcs[BISHOP] | p.pcs[QUEEN]) & them;
+    while (diag) {
+        int s = lsb(diag);
+        diag &= diag - 1;
+        d |= bishop_attacks(s, occ_no_king);
+    }
+    bb_t orth = (p.pcs[ROOK] | p.pcs[QUEEN]) & them;
+    while (orth) {
+        int s = lsb(orth);
+        orth &= orth - 1;
+        d |= rook_attacks(s, occ_no_king);
+    }
+    return d;
+}
+
 struct GenCtx {
     const Position* p;
     int king;        // -1 if none
-    bb_t blockers;
+    bb_t blockers;   // our pieces pinned against our king (python-chess _slider_blockers)
+    bb_t danger;     // danger_map of the opponent
     MoveList* out;
 };
-// python-chess _is_safe(king, blockers, move) (ep handled exactly by ep_is_legal)
-SC_HD void emit_if_safe(GenCtx& g, int from, int to, int promo, bool is_ep, bool is_castle) {
-    const Position& p = *g.p;
-    bool ok;
-    if (g.king < 0) ok = true;
-    else if (from == g.king) ok = is_castle || attackers_mask(p, !p.turn, to, all_occ(p)) == 0;
-    else if (is_ep) ok = ep_is_legal(p, from);
-    else ok = !(g.blockers & bit(from)) || (line_through(from, to) & bit(g.king));
-    if (ok && g.out->n < MAX_MOVES) g.out->m[g.out->n++] = mk_move(from, to, promo);
+SC_HD void emit(GenCtx& g, int from, int to, int promo) {
+    if (g.out->n < MAX_MOVES) g.out->m[g.out->n++] = mk_move(from, to, promo);
+}
+// python-chess _is_safe for a non-king, non-ep move, as a mask of allowed targets: a pinned piece stays on the
+// line through itself and the king
+SC_HD bb_t pin_mask(const GenCtx& g, int from) {
+    if (g.king < 0 || !(g.blockers & bit(from))) return BB_ALL;
+    return line_through(from, g.king);
 }
 SC_HD void emit_pawn(GenCtx& g, int from, int to) {
     if ((to >> 3) == 0 || (to >> 3) == 7) {
-        emit_if_safe(g, from, to, 5, false, false);
-        emit_if_safe(g, from, to, 4, false, false);
-        emit_if_safe(g, from, to, 3, false, false);
-        emit_if_safe(g, from, to, 2, false, false);
+        emit(g, from, to, 5);
+        emit(g, from, to, 4);
+        emit(g, from, to, 3);
+        emit(g, from, to, 2);
     } else
-        emit_if_safe(g, from, to, 0, false, false);
+        emit(g, from, to, 0);
 }
 SC_HD void gen_ep(GenCtx& g, bb_t from_mask, bb_t to_mask) {
     const Position& p = *g.p;
@@ -352,7 +397,7 @@ SC_HD void gen_ep(GenCtx& g, bb_t from_mask, bb_t to_mask) {
     while (c) {
         int from = msb(c);
         c ^= bit(from);
-        emit_if_safe(g, from, p.ep, 0, true, false);
+        if (ep_is_legal(p, from)) emit(g, from, p.ep, 0);
     }
 }
 // python-chess generate_castling_moves (standard chess)
@@ -360,36 +405,34 @@ SC_HD void gen_castling(GenCtx& g, bb_t from_mask, bb_t to_mask) {
     const Position& p = *g.p;
     int us = p.turn, base = us ? 0 : 56, ksq = base + 4;
     bb_t kbb = bit(ksq);
-    if (!(p.pcs[KING] & p.occ[us] & kbb & from_mask)) return;
-    bb_t occ = all_occ(p), occ_nk = occ ^ kbb;
+    if (!(p.pcs[KING] & occ_c(p, us) & kbb & from_mask)) return;
+    bb_t occ = all_occ(p);
     uint8_t kbit = us ? 1 : 4, qbit = us ? 2 : 8;
-    bb_t rooks = p.pcs[ROOK] & p.occ[us];
+    bb_t rooks = p.pcs[ROOK] & occ_c(p, us);
     if ((p.castling & kbit) && (rooks & bit(base + 7)) && (to_mask & bit(base + 7))) {
-        if (!(occ & (bit(base + 5) | bit(base + 6))) && !attackers_mask(p, !us, ksq, occ_nk) &&
-            !attackers_mask(p, !us, base + 5, occ_nk) && !attackers_mask(p, !us, base + 6, occ_nk))
-            emit_if_safe(g, ksq, base + 6, 0, false, true);
+        if (!(occ & (bit(base + 5) | bit(base + 6))) && !(g.danger & (kbb | bit(base + 5) | bit(base + 6)))) emit(g, ksq, base + 6, 0);
     }
     if ((p.castling & qbit) && (rooks & bit(base + 0)) && (to_mask & bit(base + 0))) {
-        if (!(occ & (bit(base + 1) | bit(base + 2) | bit(base + 3))) && !attackers_mask(p, !us, ksq, occ_nk) &&
-            !attackers_mask(p, !us, base + 3, occ_nk) && !attackers_mask(p, !us, base + 2, occ_nk))
-            emit_if_safe(g, ksq, base + 2, 0, false, true);
+        if (!(occ & (bit(base + 1) | bit(base + 2) | bit(base + 3))) && !(g.danger & (kbb | bit(base + 3) | bit(base + 2))))
+            emit(g, ksq, base + 2, 0);
     }
 }
-// python-chess generate_pseudo_legal_moves(from_mask, to_mask), each move filtered by _is_safe
+// python-chess generate_pseudo_legal_moves(from_mask, to_mask) with _is_safe folded in as target masks
 SC_HD void gen_pseudo(GenCtx& g, bb_t from_mask, bb_t to_mask) {
     const Position& p = *g.p;
     int us = p.turn;
-    bb_t ours = p.occ[us], theirs = p.occ[!us], occ = ours | theirs;
+    bb_t ours = occ_c(p, us), theirs = occ_c(p, !us), occ = ours | theirs;
     bb_t non_pawns = ours & ~p.pcs[PAWN] & from_mask;
     while (non_pawns) {
         int from = msb(non_pawns);
         non_pawns ^= bit(from);
         int t = piece_type_at(p, from);
         bb_t moves = piece_attacks(p, from, t, us, occ) & ~ours & to_mask;
+        moves &= (from == g.king) ? ~g.danger : pin_mask(g, from);
         while (moves) {
             int to = msb(moves);
             moves ^= bit(to);
-            emit_if_safe(g, from, to, 0, false, false);
+            emit(g, from, to, 0);
         }
     }
     if (from_mask & p.pcs[KING]) gen_castling(g, from_mask, to_mask);
@@ -399,7 +442,7 @@ SC_HD void gen_pseudo(GenCtx& g, bb_t from_mask, bb_t to_mask) {
     while (capturers) {
         int from = msb(capturers);
         capturers ^= bit(from);
-        bb_t targets = pawn_attacks_bb(us, bit(from)) & theirs & to_mask;
+        bb_t targets = pawn_attacks_bb(us, bit(from)) & theirs & to_mask & pin_mask(g, from);
         while (targets) {
             int to = msb(targets);
             targets ^= bit(to);
@@ -416,15 +459,21 @@ SC_HD void gen_pseudo(GenCtx& g, bb_t from_mask, bb_t to_mask) {
     }
     single &= to_mask;
     dbl &= to_mask;
+    // a pinned pawn may only push along the pin line (i.e. a file pin)
+    bb_t pinned = g.king >= 0 ? (g.blockers & pawns) : 0;
     while (single) {
         int to = msb(single);
         single ^= bit(to);
-        emit_pawn(g, to + (us ? -8 : 8), to);
+        int from = to + (us ? -8 : 8);
+        if ((pinned & bit(from)) && !(line_through(from, g.king) & bit(to))) continue;
+        emit_pawn(g, from, to);
     }
     while (dbl) {
         int to = msb(dbl);
         dbl ^= bit(to);
-        emit_if_safe(g, to + (us ? -16 : 16), to, 0, false, false);
+        int from = to + (us ? -16 : 16);
+        if ((pinned & bit(from)) && !(line_through(from, g.king) & bit(to))) continue;
+        emit(g, from, to, 0);
     }
     if (p.ep >= 0) gen_ep(g, from_mask, to_mask);
 }
@@ -436,36 +485,30 @@ SC_HD bool gen_legal(const Position& p, MoveList& out) {
     g.p = &p;
     g.out = &out;
     int us = p.turn;
-    bb_t kbb = p.pcs[KING] & p.occ[us];
+    bb_t kbb = p.pcs[KING] & occ_c(p, us);
     if (!kbb) {
         g.king = -1;
         g.blockers = 0;
+        g.danger = 0;
         gen_pseudo(g, BB_ALL, BB_ALL);
         return false;
     }
     int king = msb(kbb);
+    bb_t occ = all_occ(p);
     g.king = king;
     g.blockers = slider_blockers(p, king);
-    bb_t occ = all_occ(p);
-    bb_t checkers = attackers_mask(p, !us, king, occ);
-    if (!checkers) {
+    g.danger = danger_map(p, !us, occ ^ kbb);
+    if (!(g.danger & kbb)) {
         gen_pseudo(g, BB_ALL, BB_ALL);
         return false;
     }
-    // _generate_evasions
-    bb_t sliders = checkers & (p.pcs[BISHOP] | p.pcs[ROOK] | p.pcs[QUEEN]);
-    bb_t attacked = 0;
-    bb_t s = sliders;
-    while (s) {
-        int c = msb(s);
-        s ^= bit(c);
-        attacked |= line_through(king, c) & ~bit(c);
-    }
-    bb_t kt = king_attacks_bb(kbb) & ~p.occ[us] & ~attacked;
+    // _generate_evasions: king steps first, then (single checker) captures / interpositions, then ep
+    bb_t checkers = attackers_mask(p, !us, king, occ);
+    bb_t kt = king_attacks_bb(kbb) & ~occ_c(p, us) & ~g.danger;
     while (kt) {
         int to = msb(kt);
         kt ^= bit(to);
-        emit_if_safe(g, king, to, 0, false, false);
+        emit(g, king, to, 0);
     }
     int checker = msb(checkers);
     if (bit(checker) == checkers) {
@@ -481,9 +524,9 @@ SC_HD bool gen_legal(const Position& p, MoveList& out) {
 
 // python-chess has_insufficient_material(color)
 SC_HD bool insufficient_side(const Position& p, int color) {
-    bb_t own = p.occ[color];
+    bb_t own = occ_c(p, color);
     if (own & (p.pcs[PAWN] | p.pcs[ROOK] | p.pcs[QUEEN])) return false;
-    if (own & p.pcs[KNIGHT]) return popcnt(own) <= 2 && !(p.occ[!color] & ~p.pcs[KING] & ~p.pcs[QUEEN]);
+    if (own & p.pcs[KNIGHT]) return popcnt(own) <= 2 && !(occ_c(p, !color) & ~p.pcs[KING] & ~p.pcs[QUEEN]);
     if (own & p.pcs[BISHOP]) {
         const bb_t dark = 0xAA55AA55AA55AA55ULL;
         bool same = !(p.pcs[BISHOP] & dark) || !(p.pcs[BISHOP] & ~dark);

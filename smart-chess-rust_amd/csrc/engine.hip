@@ -326,9 +326,19 @@ struct sc_selfplay {
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     bool have_span = false;
     int64_t nn_launches = 0;
+    bool pending_final = false;
     scnn::bf16_t* d_hval = nullptr;  // value-head features of the current leaves [n_slots][64][256]
     float* d_vpart = nullptr;        // split-K partials of value_head.ffn.0 [ksplit][n_slots][128]
 };
+
+// complete the last enqueued simulation (expand / backward / ply transition) so that host reads see a
+// fully backed-up state; a following enqueue would have done the same work in its first launch
+static void sp_flush(sc_selfplay* sp) {
+    if (sp->pending_final) {
+        scl::mcts(sp->p, 1, 0, sp->stream);
+        sp->pending_final = false;
+    }
+}
 
 template <class T>
 static int sp_alloc(sc_selfplay* sp, T** ptr, size_t n, bool zero = true) {
@@ -356,7 +366,7 @@ int sc_selfplay_create(sc_engine* e, int device_id, const sc_selfplay_config* cf
     sp->engine = e;
     sp->device = dev;
     sp->cfg = *cfg;
-    if (e) {
+    if (e && !cfg->own_stream) {
         sp->stream = e->stream;
     } else {
         HIPOK(hipStreamCreateWithFlags(&sp->stream, hipStreamNonBlocking));
@@ -377,7 +387,7 @@ int sc_selfplay_create(sc_engine* e, int device_id, const sc_selfplay_config* cf
     p.seed = cfg->seed;
     p.first_game_id = cfg->first_game_id;
     p.node_cap = 1 + cfg->rollout_num * 218;         // worst case: every expansion adds 218 children
-    p.max_depth = cfg->rollout_num + 2;
+    p.max_depth = std::min(cfg->rollout_num + 2, 1024);  // the path is tracked in LDS (mcts_kernels.hpp DEPTH_LDS)
     p.hist_cap = cfg->num_steps + 2 + 600;           // room for sc_selfplay_set_position prefixes
     p.tpos_cap = cfg->rollout_num + 2;
     p.trace_cap = cfg->trace_capacity > 0 ? std::min(cfg->n_games, std::max(cfg->trace_capacity, 2 * cfg->n_slots)) : cfg->n_games;
@@ -393,9 +403,7 @@ int sc_selfplay_create(sc_engine* e, int device_id, const sc_selfplay_config* cf
     rc |= sp_alloc(sp, &p.P, G * NC, false);
     rc |= sp_alloc(sp, &p.U, G * NC, false);
     rc |= sp_alloc(sp, &p.MV, G * NC, false);
-    rc |= sp_alloc(sp, &p.NC, G * NC, false);
-    rc |= sp_alloc(sp, &p.FC, G * NC, false);
-    rc |= sp_alloc(sp, &p.PS, G * NC, false);
+    rc |= sp_alloc(sp, &p.H, G * NC, false);
     rc |= sp_alloc(sp, &p.boards, G * 7168);
     rc |= sp_alloc(sp, &p.meta, G * 8);
     rc |= sp_alloc(sp, &p.legal_mv, G * 224);
@@ -443,6 +451,9 @@ int sc_selfplay_create(sc_engine* e, int device_id, const sc_selfplay_config* cf
         p.vf_fc2w = (uint32_t)e->net.f_fc2w;
         p.vf_fc2b = (uint32_t)e->net.f_fc2b;
     }
+    // the zero-fills above ran on the NULL stream, which does not order against the (non-blocking) launch
+    // stream: make them complete before the first kernel touches the buffers
+    HIPOK(hipDeviceSynchronize());
     scl::init_slots(p, sp->stream);
     HIPOK(hipGetLastError());
     HIPOK(hipStreamSynchronize(sp->stream));
@@ -527,16 +538,27 @@ int sc_selfplay_enqueue_sims(sc_selfplay* sp, int n) {
             sp->nn_launches++;
         }
     }
-    if (n > 0) scl::mcts(p, 1, 0, s);  // leave every game fully backed up
+    if (n > 0) sp->pending_final = true;  // the last simulation is completed lazily (sp_flush) before any host read
     sp->sim_steps_enqueued += n;
     if (sp->timing_stride > 0) HIPOK(hipEventRecord(sp->ev_end, s));
     HIPOK(hipGetLastError());
     return 0;
 }
 
+int sc_selfplay_enqueue_interleaved(sc_selfplay** handles, int n_handles, int n) {
+    if (!handles || n_handles <= 0 || n < 0) return fail("bad argument");
+    for (int i = 0; i < n; i++)
+        for (int h = 0; h < n_handles; h++) {
+            int rc = sc_selfplay_enqueue_sims(handles[h], 1);
+            if (rc) return rc;
+        }
+    return 0;
+}
+
 int sc_selfplay_synchronize(sc_selfplay* sp) {
     if (!sp) return fail("null handle");
     HIPOK(hipSetDevice(sp->device));
+    sp_flush(sp);
     HIPOK(hipStreamSynchronize(sp->stream));
     return 0;
 }
@@ -544,6 +566,7 @@ int sc_selfplay_synchronize(sc_selfplay* sp) {
 int sc_selfplay_get_stats(sc_selfplay* sp, sc_selfplay_stats* out) {
     if (!sp || !out) return fail("bad argument");
     HIPOK(hipSetDevice(sp->device));
+    sp_flush(sp);
     HIPOK(hipStreamSynchronize(sp->stream));
     sc::Counters c;
     HIPOK(hipMemcpy(&c, sp->p.cnt, sizeof c, hipMemcpyDeviceToHost));
@@ -581,6 +604,7 @@ int sc_selfplay_run(sc_selfplay* sp, int64_t max_sim_steps) {
 int sc_selfplay_timing(sc_selfplay* sp, int reset, float* ms_total, float* ms_nn, int64_t* nn_launches) {
     if (!sp) return fail("null handle");
     HIPOK(hipSetDevice(sp->device));
+    sp_flush(sp);
     HIPOK(hipStreamSynchronize(sp->stream));
     float tot = 0.f, nn = 0.f;
     int64_t cnt = std::min<int64_t>(sp->ev_recorded, 4096);
@@ -610,6 +634,7 @@ int sc_selfplay_get_trace(sc_selfplay* sp, int game, sc_trace_info* info, uint16
     if (!sp || !info || game < 0 || game >= sp->p.total_games) return fail("bad argument");
     game %= sp->p.trace_cap;
     HIPOK(hipSetDevice(sp->device));
+    sp_flush(sp);
     HIPOK(hipStreamSynchronize(sp->stream));
     const sc::SpParams& p = sp->p;
     sc::TraceHdr h;
@@ -682,6 +707,7 @@ int sc_selfplay_get_tree(sc_selfplay* sp, int slot, int cap, int32_t* n, float* 
                          int32_t* first_child, int32_t* n_child) {
     if (!sp || slot < 0 || slot >= sp->p.n_slots) return fail("bad argument");
     HIPOK(hipSetDevice(sp->device));
+    sp_flush(sp);
     HIPOK(hipStreamSynchronize(sp->stream));
     const sc::SpParams& p = sp->p;
     sc::GameCtl c;
@@ -694,11 +720,13 @@ int sc_selfplay_get_tree(sc_selfplay* sp, int slot, int cap, int32_t* n, float* 
         if (uct) HIPOK(hipMemcpy(uct, p.U + nb, (size_t)nn * 4, hipMemcpyDeviceToHost));
         if (prior) HIPOK(hipMemcpy(prior, p.P + nb, (size_t)nn * 4, hipMemcpyDeviceToHost));
         if (move) HIPOK(hipMemcpy(move, p.MV + nb, (size_t)nn * 2, hipMemcpyDeviceToHost));
-        if (first_child) HIPOK(hipMemcpy(first_child, p.FC + nb, (size_t)nn * 4, hipMemcpyDeviceToHost));
-        if (n_child) {
-            std::vector<uint16_t> t((size_t)nn);
-            HIPOK(hipMemcpy(t.data(), p.NC + nb, (size_t)nn * 2, hipMemcpyDeviceToHost));
-            for (int i = 0; i < nn; i++) n_child[i] = t[(size_t)i];
+        if (first_child || n_child) {
+            std::vector<sc::NodeHdr> t((size_t)nn);
+            HIPOK(hipMemcpy(t.data(), p.H + nb, (size_t)nn * sizeof(sc::NodeHdr), hipMemcpyDeviceToHost));
+            for (int i = 0; i < nn; i++) {
+                if (first_child) first_child[i] = t[(size_t)i].fc;
+                if (n_child) n_child[i] = t[(size_t)i].nc;
+            }
         }
     }
     return c.n_nodes;
@@ -708,6 +736,7 @@ int sc_selfplay_get_slot(sc_selfplay* sp, int slot, int32_t* ply, int32_t* sim, 
                          int32_t* last_path, int32_t* last_path_len) {
     if (!sp || slot < 0 || slot >= sp->p.n_slots) return fail("bad argument");
     HIPOK(hipSetDevice(sp->device));
+    sp_flush(sp);
     HIPOK(hipStreamSynchronize(sp->stream));
     sc::GameCtl c;
     HIPOK(hipMemcpy(&c, sp->p.ctl + slot, sizeof c, hipMemcpyDeviceToHost));
@@ -725,6 +754,7 @@ int sc_selfplay_get_slot(sc_selfplay* sp, int slot, int32_t* ply, int32_t* sim, 
 int sc_selfplay_set_noise(sc_selfplay* sp, int slot, const float* noise, int n) {
     if (!sp || slot < 0 || slot >= sp->p.n_slots || n < 0 || n > 224) return fail("bad argument");
     HIPOK(hipSetDevice(sp->device));
+    sp_flush(sp);
     HIPOK(hipStreamSynchronize(sp->stream));
     HIPOK(hipMemcpy(sp->p.noise + (size_t)slot * 224, noise, (size_t)n * 4, hipMemcpyHostToDevice));
     return 0;
@@ -732,6 +762,7 @@ int sc_selfplay_set_noise(sc_selfplay* sp, int slot, const float* noise, int n) 
 int sc_selfplay_get_noise(sc_selfplay* sp, int slot, float* noise, int cap) {
     if (!sp || slot < 0 || slot >= sp->p.n_slots) return fail("bad argument");
     HIPOK(hipSetDevice(sp->device));
+    sp_flush(sp);
     HIPOK(hipStreamSynchronize(sp->stream));
     HIPOK(hipMemcpy(noise, sp->p.noise + (size_t)slot * 224, (size_t)std::min(cap, 224) * 4, hipMemcpyDeviceToHost));
     return 0;
@@ -740,6 +771,7 @@ int sc_selfplay_get_noise(sc_selfplay* sp, int slot, float* noise, int cap) {
 int sc_selfplay_set_position(sc_selfplay* sp, int slot, const uint16_t* moves, int n_moves) {
     if (!sp || slot < 0 || slot >= sp->p.n_slots || n_moves < 0 || n_moves > 590) return fail("bad argument");
     HIPOK(hipSetDevice(sp->device));
+    sp_flush(sp);
     uint16_t* d_moves = nullptr;
     HIPOK(dalloc(&d_moves, (size_t)n_moves));
     if (n_moves) HIPOK(hipMemcpy(d_moves, moves, (size_t)n_moves * 2, hipMemcpyHostToDevice));
@@ -751,5 +783,21 @@ int sc_selfplay_set_position(sc_selfplay* sp, int slot, const uint16_t* moves, i
 }
 
 int sc_move_uci(uint16_t move, char* buf8) { return sctrace::move_uci(move, buf8); }
+
+/* developer aid (not in the public header): cycle stamps of the last k_mcts launch, out[n_slots][8] */
+int sc_selfplay_debug_cycles(sc_selfplay* sp, int enable, unsigned long long* out) {
+    if (!sp) return fail("null handle");
+    HIPOK(hipSetDevice(sp->device));
+    HIPOK(hipStreamSynchronize(sp->stream));
+    if (enable && !sp->p.dbg_cycles) {
+        HIPOK(dalloc(&sp->p.dbg_cycles, (size_t)sp->p.n_slots * 8));
+        sp->allocs.push_back(sp->p.dbg_cycles);
+        HIPOK(hipMemset(sp->p.dbg_cycles, 0, (size_t)sp->p.n_slots * 64));
+        HIPOK(hipDeviceSynchronize());
+    }
+    if (out && sp->p.dbg_cycles)
+        HIPOK(hipMemcpy(out, sp->p.dbg_cycles, (size_t)sp->p.n_slots * 64, hipMemcpyDeviceToHost));
+    return 0;
+}
 
 }  // extern "C"

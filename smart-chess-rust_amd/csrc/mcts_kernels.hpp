@@ -39,19 +39,69 @@ __device__ inline unsigned long long wave_sum_u64(unsigned long long v) {
     return v;
 }
 
+// Promote a wave-uniform value to SGPRs.  All lanes of a game's wave run the scalar chess logic on identical
+// data; telling the compiler so (readfirstlane) moves that logic -- 64-bit bitboard arithmetic, bit scans, bit
+// reversal, loop control -- from the vector ALU (2 x 32-bit ops, exec-mask branches) onto the scalar unit.
+__device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ bb_t uniform(bb_t v) {
+    unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
+    unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+    return ((bb_t)hi << 32) | lo;
+}
+__device__ __forceinline__ Position uniform(const Position& q) {
+    Position r;
+#pragma unroll
+    for (int t = 0; t < 6; t++) r.pcs[t] = uniform(q.pcs[t]);
+    r.occ[0] = uniform(q.occ[0]);
+    r.occ[1] = uniform(q.occ[1]);
+    r.key = uniform(q.key);
+    r.turn = (uint8_t)uniform((int)q.turn);
+    r.castling = (uint8_t)uniform((int)q.castling);
+    r.ep = (int8_t)uniform((int)q.ep);
+    r.flags = (uint8_t)uniform((int)q.flags);
+    r.halfmove = (uint16_t)uniform((int)q.halfmove);
+    r.fullmove = (uint16_t)uniform((int)q.fullmove);
+    return r;
+}
+__device__ __forceinline__ NodeHdr uniform(const NodeHdr& q) {
+    NodeHdr r;
+    r.fc = uniform(q.fc);
+    r.nc = (uint16_t)uniform((int)q.nc);
+    r.ps = (uint16_t)uniform((int)q.ps);
+    return r;
+}
+__device__ __forceinline__ GameCtl uniform(const GameCtl& q) {
+    GameCtl r;
+    r.status = uniform(q.status);
+    r.ply = uniform(q.ply);
+    r.sim = uniform(q.sim);
+    r.n_nodes = uniform(q.n_nodes);
+    r.n_exp = uniform(q.n_exp);
+    r.leaf = uniform(q.leaf);
+    r.path_len = uniform(q.path_len);
+    r.leaf_kind = uniform(q.leaf_kind);
+    r.n_legal = uniform(q.n_legal);
+    r.leaf_value = __builtin_bit_cast(float, uniform(__builtin_bit_cast(int, q.leaf_value)));
+    r.err = (uint32_t)uniform((int)q.err);
+    r.trace_slot = uniform(q.trace_slot);
+    r.game_id = uniform((bb_t)q.game_id);
+    r.start_ply = uniform(q.start_ply);
+    r.pad = 0;
+    return r;
+}
+
 // chain of positions: game history, then the tree path, then the leaf being created
 struct DevChain {
     const Position* hist;
     int root_ply;
     const Position* tpos;
-    const uint16_t* PS;      // node -> tpos slot (slot-local pool)
-    const int32_t* path;     // path[d] = node at depth d
+    const uint16_t* ps_by_depth;  // LDS: tpos slot of the path node at depth d (expanded nodes only)
     const Position* leaf;
     int leaf_idx;
     __device__ const Position& pos(int i) const {
         if (i <= root_ply) return hist[i];
         if (i == leaf_idx) return *leaf;
-        return tpos[PS[path[i - root_ply]]];
+        return tpos[ps_by_depth[i - root_ply]];
     }
 };
 struct HistChain {
@@ -86,20 +136,31 @@ __device__ inline uint8_t rep_flags_wave(const Chain& ch, int idx, bb_t key0, in
     return (uint8_t)((matches >= 1 ? F_REP2 : 0) | (matches >= 2 ? F_REP3 : 0));
 }
 
-// _encode (src/chess.rs:845-877) for the position at chain index idx: lane = output pixel.
-// stage: 7168 B of LDS; out: int8[64][112] in HBM.
+// Stage the <=8 positions _encode looks at (idx, idx-1, ...) into LDS with two dependent round trips in total:
+// lane l fetches 8-byte word (l & 7) [and word 8/9 for l&7 < 2] of history entry l >> 3.
 template <class Chain>
-__device__ inline void encode_wave(const Chain& ch, int idx, int lane, int8_t* stage, int8_t* out, int32_t* meta_out) {
+__device__ inline void stage_history(const Chain& ch, int idx, int lane, Position* s_hist) {
+    const int j = lane >> 3, w = lane & 7;
+    if (j <= idx) {
+        const unsigned long long* src = reinterpret_cast<const unsigned long long*>(&ch.pos(idx - j));
+        unsigned long long* dst = reinterpret_cast<unsigned long long*>(&s_hist[j]);
+        dst[w] = src[w];
+        if (w < 2) dst[8 + w] = src[8 + w];
+    }
+}
+
+// _encode (src/chess.rs:845-877) for the position at history depth 0 of s_hist (newest first): lane = output
+// pixel.  stage: 7168 B of LDS; out: int8[64][112] in HBM.
+__device__ inline void encode_wave(const Position* s_hist, int n_hist, int lane, int8_t* stage, int8_t* out, int32_t* meta_out) {
     uint4* cell16 = reinterpret_cast<uint4*>(stage + lane * 112);
 #pragma unroll
     for (int k = 0; k < 7; k++) cell16[k] = make_uint4(0, 0, 0, 0);
     int8_t* cell = stage + lane * 112;
-    const Position& cur = ch.pos(idx);
-    int turn = cur.turn;
+    const int turn = s_hist[0].turn;
     int src = turn == BLACK ? (lane ^ 56) : lane;
     bb_t sb = bit(src);
-    for (int j = 0; j < 8 && j <= idx; j++) {
-        const Position& h = ch.pos(idx - j);
+    for (int j = 0; j < n_hist; j++) {
+        const Position& h = s_hist[j];
         bb_t ow = h.occ[WHITE], ob = h.occ[BLACK];
         if ((ow | ob) & sb) {
             int t = 0;
@@ -119,7 +180,7 @@ __device__ inline void encode_wave(const Chain& ch, int idx, int lane, int8_t* s
     for (int k = 0; k < 7; k++) o16[k] = cell16[k];
     if (lane == 0) {
         int32_t m[7];
-        encode_meta(cur, m);
+        encode_meta(s_hist[0], m);
 #pragma unroll
         for (int k = 0; k < 7; k++) meta_out[k] = m[k];
         meta_out[7] = 0;
@@ -151,82 +212,125 @@ __device__ inline float gamma03(uint64_t st) {
 }
 
 // ------------------------------------------------------------------ select (src/mcts.rs:132-227)
-__device__ __noinline__ void dev_select(const SpParams& p, int g, int lane, int8_t* s_stage, move_t* s_moves, Position* s_leaf_p) {
+constexpr int DEPTH_LDS = 1024;  // path entries tracked in LDS (a deeper path sets ERR_DEPTH_OVERFLOW)
+
+#define SC_STAMP(k)                                                                   \
+    do {                                                                              \
+        if (p.dbg_cycles && lane == 0) p.dbg_cycles[(size_t)g * 8 + (k)] = clock64(); \
+    } while (0)
+
+__device__ __forceinline__ void dev_select(const SpParams& p, int g, int lane, int8_t* s_stage, move_t* s_moves, Position* s_leaf_p,
+                                        uint16_t* s_ps, Position* s_hist) {
     Position& s_leaf = *s_leaf_p;
+    SC_STAMP(2);
     GameCtl& c = p.ctl[g];
-    if (c.status != ST_ACTIVE) {
+    const GameCtl cs = uniform(c);  // one 64-byte fetch instead of a chain of dependent field loads
+    if (cs.status != ST_ACTIVE) {
         if (lane == 0) c.leaf_kind = LK_NONE;
         return;
     }
     const size_t nb = (size_t)g * p.node_cap;
-    int32_t* N = p.N + nb;
-    float* W = p.W + nb;
-    float* P = p.P + nb;
+    const int32_t* N = p.N + nb;
+    const float* W = p.W + nb;
+    const float* P = p.P + nb;
     float* U = p.U + nb;
-    uint16_t* MV = p.MV + nb;
-    uint16_t* NC = p.NC + nb;
-    int32_t* FC = p.FC + nb;
-    uint16_t* PS = p.PS + nb;
+    const uint16_t* MV = p.MV + nb;
+    const NodeHdr* H = p.H + nb;
     int32_t* path = p.path + (size_t)g * p.max_depth;
     const Position* hist = p.hist + (size_t)g * p.hist_cap;
     Position* tpos = p.tpos + (size_t)g * p.tpos_cap;
-    const int root_ply = c.ply;
-    const int root_turn = hist[root_ply].turn;
+    const int root_ply = cs.ply;
+    const Position root = uniform(tpos[0]);
+    const int root_turn = root.turn;
+    const int dmax = p.max_depth < DEPTH_LDS ? p.max_depth : DEPTH_LDS;
 
-    int node = 0, depth = 0;
-    if (lane == 0) path[0] = 0;
+    int node = 0, depth = 0, parent_ps = 0;
+    NodeHdr hdr = uniform(H[0]);
+    if (lane == 0) {
+        path[0] = 0;
+        s_ps[0] = 0;
+    }
     uint32_t err = 0;
     for (;;) {
-        int nc = NC[node];
+        const int nc = hdr.nc;
         if (nc == 0) break;
-        int fc = FC[node];
-        int child;
-        if (nc == 1) {
-            child = fc;
-        } else {
+        const int fc = hdr.fc;
+        // children statistics AND their headers in one round trip (lane owns children lane, lane+64, ...)
+        int cn[4];
+        float cw[4], cp[4];
+        NodeHdr ch_[4];
+        const int nr = (nc + 63) >> 6;  // rounds of 64 children (wave-uniform): usually 1
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            cn[r] = 0;
+            cw[r] = 0.f;
+            cp[r] = 0.f;
+            ch_[r] = NodeHdr{-1, 0, 0};
+            if (r < nr) {
+                int i = lane + 64 * r;
+                bool ok = i < nc;
+                cn[r] = ok ? N[fc + i] : 0;
+                cw[r] = ok ? W[fc + i] : 0.f;
+                cp[r] = ok ? P[fc + i] : 0.f;
+                ch_[r] = ok ? H[fc + i] : NodeHdr{-1, 0, 0};
+            }
+        }
+        int best_i = 0;
+        if (nc > 1) {
             // side to move at `node`: root_turn flipped per depth; reverse_q = Black to move (torch.rs:49-52)
-            bool reverse_q = ((root_turn ^ (depth & 1)) == BLACK);
-            bool noisy = depth == 0 && p.with_noise;
+            const bool reverse_q = ((root_turn ^ (depth & 1)) == BLACK);
+            const bool noisy = depth == 0 && p.with_noise;
             float* nz = p.noise + (size_t)g * MAXC;
-            if (noisy && !p.external_noise) {
-                float gsum = 0.0f;
-                float gv[4];
+            float nzv[4] = {0.f, 0.f, 0.f, 0.f};
+            if (noisy) {
+                if (!p.external_noise) {
+                    float gsum = 0.0f;
 #pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    int i = lane + 64 * r;
-                    gv[r] = 0.0f;
-                    if (i < nc) {
-                        gv[r] = gamma03(sc_rng(p.seed, c.game_id, (uint64_t)root_ply, 3, (uint64_t)c.sim * 256 + (uint64_t)i));
-                        gsum += gv[r];
+                    for (int r = 0; r < 4; r++) {
+                        int i = lane + 64 * r;
+                        if (i < nc) {
+                            nzv[r] = gamma03(sc_rng(p.seed, cs.game_id, (uint64_t)root_ply, 3, (uint64_t)cs.sim * 256 + (uint64_t)i));
+                            gsum += nzv[r];
+                        }
                     }
-                }
-                gsum = wave_sum_f(gsum);
+                    gsum = wave_sum_f(gsum);
 #pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    int i = lane + 64 * r;
-                    if (i < nc) nz[i] = gv[r] / gsum;
+                    for (int r = 0; r < 4; r++) {
+                        int i = lane + 64 * r;
+                        nzv[r] = nzv[r] / gsum;
+                        if (i < nc) nz[i] = nzv[r];
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        int i = lane + 64 * r;
+                        if (i < nc) nzv[r] = nz[i];
+                    }
                 }
             }
             int tot = 0;
-            for (int i = lane; i < nc; i += 64) tot += N[fc + i];
+#pragma unroll
+            for (int r = 0; r < 4; r++) tot += cn[r];
             tot = wave_sum_i(tot);
-            float sqrt_total = sqrtf((float)tot);
+            const float sqrt_total = sqrtf((float)tot);
             float best_u = 0.0f;
-            int best_i = -1;
-            for (int i = lane; i < nc; i += 64) {
-                float prior = P[fc + i];
-                if (noisy) prior = prior * (1.0f - p.epsilon) + nz[i] * p.epsilon;  // mcts.rs:181
-                int n = N[fc + i];
-                float q = W[fc + i];
-                // uct(): src/mcts.rs:69-75
-                float average_award = q / ((float)n + 1e-4f) * (reverse_q ? -1.0f : 1.0f);
-                float exploration = (sqrt_total + 0.01f) / (1.0f + (float)n) * p.cpuct * prior;
-                float u = average_award + exploration;
-                U[fc + i] = u;
-                if (!isfinite(u)) err |= ERR_NONFINITE_UCT;
-                if (best_i < 0 || u >= best_u) {  // later index wins ties (max_by keeps the last maximum)
-                    best_u = u;
-                    best_i = i;
+            best_i = -1;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                int i = lane + 64 * r;
+                if (r < nr && i < nc) {
+                    float prior = cp[r];
+                    if (noisy) prior = prior * (1.0f - p.epsilon) + nzv[r] * p.epsilon;  // mcts.rs:181
+                    // uct(): src/mcts.rs:69-75
+                    float average_award = cw[r] / ((float)cn[r] + 1e-4f) * (reverse_q ? -1.0f : 1.0f);
+                    float exploration = (sqrt_total + 0.01f) / (1.0f + (float)cn[r]) * p.cpuct * prior;
+                    float u = average_award + exploration;
+                    U[fc + i] = u;
+                    if (!isfinite(u)) err |= ERR_NONFINITE_UCT;
+                    if (best_i < 0 || u >= best_u) {  // later index wins ties (max_by keeps the last maximum)
+                        best_u = u;
+                        best_i = i;
+                    }
                 }
             }
             for (int o = 32; o > 0; o >>= 1) {
@@ -238,28 +342,40 @@ __device__ __noinline__ void dev_select(const SpParams& p, int g, int lane, int8
                     best_i = oi;
                 }
             }
-            child = fc + best_i;
         }
-        node = child;
+        best_i = __builtin_amdgcn_readfirstlane(best_i);
+        // header of the chosen child: owned by lane best_i & 63, register best_i >> 6
+        const int rr = best_i >> 6;
+        NodeHdr mine = rr == 0 ? ch_[0] : rr == 1 ? ch_[1] : rr == 2 ? ch_[2] : ch_[3];
+        NodeHdr nxt;
+        nxt.fc = __builtin_amdgcn_readlane(mine.fc, best_i & 63);
+        int packed = __builtin_amdgcn_readlane((int)mine.nc | ((int)mine.ps << 16), best_i & 63);
+        nxt.nc = (uint16_t)(packed & 0xffff);
+        nxt.ps = (uint16_t)((unsigned)packed >> 16);
+        parent_ps = hdr.ps;
+        node = fc + best_i;
+        hdr = nxt;
         depth++;
-        if (depth >= p.max_depth) {
+        if (depth >= dmax) {
             err |= ERR_DEPTH_OVERFLOW;
             depth--;
             break;
         }
-        if (lane == 0) path[depth] = node;
+        if (lane == 0) {
+            path[depth] = node;
+            s_ps[depth] = hdr.ps;
+        }
     }
+    SC_STAMP(3);
     unsigned long long anyerr = __ballot(err != 0);
     if (anyerr) {
         for (int o = 32; o > 0; o >>= 1) err |= __shfl_xor(err, o, 64);
         if (lane == 0) {
-            c.err |= err;
+            c.err = cs.err | err;
             atomicOr(&p.cnt->err, (int)err);
         }
     }
-    __syncthreads();  // path[] visible to all lanes
-
-    int fcl = FC[node];
+    const int fcl = hdr.fc;
     if (lane == 0) {
         c.leaf = node;
         c.path_len = depth + 1;
@@ -275,26 +391,30 @@ __device__ __noinline__ void dev_select(const SpParams& p, int g, int lane, int8
     // position of the leaf (wave-uniform)
     Position pos;
     if (depth == 0) {
-        pos = tpos[0];
+        pos = root;
     } else {
-        pos = tpos[PS[path[depth - 1]]];
-        make_move(pos, MV[node]);  // state.advance (mcts.rs:224)
+        pos = uniform(tpos[parent_ps]);
+        make_move(pos, (move_t)__builtin_amdgcn_readfirstlane((int)MV[node]));  // state.advance (mcts.rs:224)
     }
     if (lane == 0) s_leaf = pos;
-    __syncthreads();
-    DevChain ch{hist, root_ply, tpos, PS, path, &s_leaf, root_ply + depth};
+    __syncthreads();  // s_leaf, s_ps visible
+    DevChain ch{hist, root_ply, tpos, s_ps, &s_leaf, root_ply + depth};
     if (depth > 0) {
-        uint8_t rf = rep_flags_wave(ch, root_ply + depth, pos.key, lane);
+        uint8_t rf = (uint8_t)__builtin_amdgcn_readfirstlane((int)rep_flags_wave(ch, root_ply + depth, pos.key, lane));
         pos.flags = (uint8_t)((pos.flags & F_IRREV) | rf);
         __syncthreads();
         if (lane == 0) s_leaf.flags = pos.flags;
         __syncthreads();
     }
-    // scratch slot for the expansion (claimed in k_expand_backup if the leaf is not terminal)
-    if (lane == 0) tpos[c.n_exp] = pos;
+    SC_STAMP(4);
+    // history for the encoder: issued now so the loads overlap move generation
+    stage_history(ch, root_ply + depth, lane, s_hist);
+    // scratch slot for the expansion (claimed in dev_expand if the leaf is not terminal)
+    if (lane == 0) tpos[cs.n_exp] = pos;
     MoveList ml{s_moves, 0};
     bool in_check = gen_legal(pos, ml);
     __syncthreads();
+    SC_STAMP(5);
     int n = ml.n;
     if (n == 0) {
         if (lane == 0) {
@@ -319,15 +439,17 @@ __device__ __noinline__ void dev_select(const SpParams& p, int g, int lane, int8
         li[i] = (uint16_t)idx;
     }
     if (__ballot(bad) && lane == 0) {
-        c.err |= ERR_BAD_MOVE_INDEX;
+        c.err = cs.err | err | ERR_BAD_MOVE_INDEX;
         atomicOr(&p.cnt->err, ERR_BAD_MOVE_INDEX);
     }
-    encode_wave(ch, root_ply + depth, lane, s_stage, p.boards + (size_t)g * 7168, p.meta + (size_t)g * 8);
+    const int idx = root_ply + depth;
+    encode_wave(s_hist, idx < 7 ? idx + 1 : 8, lane, s_stage, p.boards + (size_t)g * 7168, p.meta + (size_t)g * 8);
     if (lane == 0) {
         c.leaf_kind = LK_EVAL;
         c.n_legal = n;
         p.n_legal[g] = n;
     }
+    SC_STAMP(6);
 }
 
 // ------------------------------------------------------------------ synthetic evaluator (tests)
@@ -372,9 +494,7 @@ __device__ inline void start_new_game(SpParams& p, int g, int lane) {
         p.P[nb] = 0.0f;
         p.U[nb] = 0.0f;
         p.MV[nb] = 0;
-        p.NC[nb] = 0;
-        p.FC[nb] = -1;
-        p.PS[nb] = 0;
+        p.H[nb] = NodeHdr{-1, 0, 0};
         c.status = ST_ACTIVE;
         c.ply = 0;
         c.start_ply = 0;
@@ -460,30 +580,29 @@ __device__ inline float value_from_partials(const SpParams& p, int g, int lane) 
     return v * (float)(meta[0] * 2 - 1);
 }
 
-__device__ __noinline__ void dev_expand(SpParams& p, int g, int lane, Position* s_np_p) {
+__device__ __forceinline__ void dev_expand(SpParams& p, int g, int lane, Position* s_np_p) {
     Position& s_np = *s_np_p;
     GameCtl& c = p.ctl[g];
-    if (c.status != ST_ACTIVE || c.leaf_kind == LK_NONE) return;
+    const GameCtl cs = uniform(c);  // one 64-byte fetch instead of a chain of dependent field loads
+    if (cs.status != ST_ACTIVE || cs.leaf_kind == LK_NONE) return;
     const size_t nb = (size_t)g * p.node_cap;
     int32_t* N = p.N + nb;
     float* W = p.W + nb;
     float* P = p.P + nb;
     float* U = p.U + nb;
     uint16_t* MV = p.MV + nb;
-    uint16_t* NC = p.NC + nb;
-    int32_t* FC = p.FC + nb;
-    uint16_t* PS = p.PS + nb;
+    NodeHdr* H = p.H + nb;
     const int32_t* path = p.path + (size_t)g * p.max_depth;
     Position* hist = p.hist + (size_t)g * p.hist_cap;
     Position* tpos = p.tpos + (size_t)g * p.tpos_cap;
 
-    const int leaf = c.leaf, kind = c.leaf_kind, plen = c.path_len;
-    float value = c.leaf_value;
-    int n_nodes = c.n_nodes, n_exp = c.n_exp;
+    const int leaf = cs.leaf, kind = cs.leaf_kind, plen = cs.path_len;
+    float value = cs.leaf_value;
+    int n_nodes = cs.n_nodes, n_exp = cs.n_exp;
     uint32_t err = 0;
     if (kind == LK_EVAL) {
         value = p.vf_fused ? value_from_partials(p, g, lane) : p.value[g];
-        int n = c.n_legal;
+        int n = cs.n_legal;
         if (n_nodes + n > p.node_cap || n_exp + 1 >= p.tpos_cap) {
             err = ERR_POOL_OVERFLOW;
         } else {
@@ -496,20 +615,14 @@ __device__ __noinline__ void dev_expand(SpParams& p, int g, int lane, Position* 
                 P[id] = pr[i];
                 U[id] = 0.0f;
                 MV[id] = lm[i];
-                NC[id] = 0;
-                FC[id] = -1;
-                PS[id] = 0;
+                H[id] = NodeHdr{-1, 0, 0};
             }
-            if (lane == 0) {
-                FC[leaf] = n_nodes;
-                NC[leaf] = (uint16_t)n;
-                PS[leaf] = (uint16_t)n_exp;
-            }
+            if (lane == 0) H[leaf] = NodeHdr{n_nodes, (uint16_t)n, (uint16_t)n_exp};
             n_nodes += n;
             n_exp += 1;
         }
     } else if (kind == LK_TERM_NEW) {
-        if (lane == 0) FC[leaf] = value == 0.0f ? -2 : value > 0.0f ? -3 : -4;
+        if (lane == 0) H[leaf] = NodeHdr{value == 0.0f ? -2 : value > 0.0f ? -3 : -4, 0, 0};
     }
     // backward (mcts.rs:90-98): every node of the path, root included
     for (int d = lane; d < plen; d += 64) {
@@ -518,14 +631,14 @@ __device__ __noinline__ void dev_expand(SpParams& p, int g, int lane, Position* 
         W[nd] += value;
     }
     __syncthreads();
-    int sim = c.sim + 1;
+    int sim = cs.sim + 1;
     if (lane == 0) {
         c.n_nodes = n_nodes;
         c.n_exp = n_exp;
         c.sim = sim;
         c.leaf_kind = LK_NONE;
         if (err) {
-            c.err |= err;
+            c.err = cs.err | err;
             atomicOr(&p.cnt->err, (int)err);
         }
         atomicAdd(&p.cnt->sims_done, 1ULL);
@@ -536,8 +649,9 @@ __device__ __noinline__ void dev_expand(SpParams& p, int g, int lane, Position* 
     // ---------------- end of this ply's search (main.rs:198-233)
     __threadfence_block();
     __syncthreads();
-    const int ply = c.ply;
-    const int nc = NC[0], fc = FC[0];
+    const int ply = cs.ply;
+    const NodeHdr h0 = H[0];
+    const int nc = h0.nc, fc = h0.fc;
     if (nc == 0) {
         // mcts::step -> None: no children => no legal moves (main.rs:213-216)
         HistChain hc{hist};
@@ -546,8 +660,8 @@ __device__ __noinline__ void dev_expand(SpParams& p, int g, int lane, Position* 
         finish_game(p, g, lane, term != T_NONE, term, winner);
         return;
     }
-    const int ts = c.trace_slot;
-    const size_t tstep = (size_t)ts * p.num_steps + (size_t)(ply - c.start_ply);
+    const int ts = cs.trace_slot;
+    const size_t tstep = (size_t)ts * p.num_steps + (size_t)(ply - cs.start_ply);
     for (int i = lane; i < nc; i += 64) {
         p.t_cmove[tstep * MAXC + i] = MV[fc + i];
         p.t_cn[tstep * MAXC + i] = N[fc + i];
@@ -555,7 +669,7 @@ __device__ __noinline__ void dev_expand(SpParams& p, int g, int lane, Position* 
         p.t_cu[tstep * MAXC + i] = U[fc + i];
     }
     // mcts::step (mcts.rs:298-317)
-    float temperature = (ply - c.start_ply) < p.temp_switch ? 1.0f : p.temperature;
+    float temperature = (ply - cs.start_ply) < p.temp_switch ? 1.0f : p.temperature;
     int choice = 0;
     if (temperature == 0.0f) {
         int bn = -1, bi = 0x7fffffff;
@@ -583,7 +697,7 @@ __device__ __noinline__ void dev_expand(SpParams& p, int g, int lane, Position* 
             float n = (float)N[fc + i];
             total += power == 1.0f ? n : powf(n, power);
         }
-        float u = (float)(sc_rng(p.seed, c.game_id, (uint64_t)ply, 1, 0) >> 40) / 16777216.0f;
+        float u = (float)(sc_rng(p.seed, cs.game_id, (uint64_t)ply, 1, 0) >> 40) / 16777216.0f;
         float x = u * total;
         float cum = 0.0f;
         int idx = 0;
@@ -601,12 +715,12 @@ __device__ __noinline__ void dev_expand(SpParams& p, int g, int lane, Position* 
         p.t_nchild[tstep] = nc;
     }
     // advance the game line
-    Position np = hist[ply];
-    make_move(np, mv);
+    Position np = uniform(hist[ply]);
+    make_move(np, (move_t)uniform((int)mv));
     if (lane == 0) s_np = np;
     __syncthreads();
     {
-        DevChain ch{hist, ply, tpos, PS, path, &s_np, ply + 1};
+        DevChain ch{hist, ply, tpos, nullptr, &s_np, ply + 1};
         uint8_t rf = rep_flags_wave(ch, ply + 1, np.key, lane);
         np.flags = (uint8_t)((np.flags & F_IRREV) | rf);
     }
@@ -619,7 +733,7 @@ __device__ __noinline__ void dev_expand(SpParams& p, int g, int lane, Position* 
     __syncthreads();
     const int new_ply = ply + 1;
     if (lane == 0) c.ply = new_ply;
-    const int i_step = ply - c.start_ply;  // the reference's loop index i
+    const int i_step = ply - cs.start_ply;  // the reference's loop index i
     if (i_step > p.outcome_gate) {         // main.rs:223-228
         HistChain hc{hist};
         int winner = -1;
@@ -643,9 +757,7 @@ __device__ __noinline__ void dev_expand(SpParams& p, int g, int lane, Position* 
         P[0] = 0.0f;
         U[0] = 0.0f;
         MV[0] = mv;
-        NC[0] = 0;
-        FC[0] = -1;
-        PS[0] = 0;
+        H[0] = NodeHdr{-1, 0, 0};
         c.n_nodes = 1;
         c.n_exp = 1;
         c.sim = 0;
@@ -659,12 +771,16 @@ __global__ __launch_bounds__(64) void k_mcts(SpParams p, int do_expand, int do_s
     __shared__ __attribute__((aligned(16))) int8_t s_stage[7168];
     __shared__ move_t s_moves[MAXC];
     __shared__ Position s_pos;
+    __shared__ Position s_hist[8];
+    __shared__ uint16_t s_ps[DEPTH_LDS];
+    SC_STAMP(0);
     if (do_expand) {
         dev_expand(p, g, lane, &s_pos);
         __threadfence_block();
         __syncthreads();
     }
-    if (do_select) dev_select(p, g, lane, s_stage, s_moves, &s_pos);
+    SC_STAMP(1);
+    if (do_select) dev_select(p, g, lane, s_stage, s_moves, &s_pos, s_ps, s_hist);
 }
 
 // ------------------------------------------------------------------ sc_selfplay_set_position
@@ -683,7 +799,7 @@ __global__ __launch_bounds__(64) void k_set_position(SpParams p, int g, const ui
         make_move(cur, moves[i]);
         if (lane == 0) s_np = cur;
         __syncthreads();
-        DevChain ch{hist, i, tpos, p.PS, p.path, &s_np, i + 1};
+        DevChain ch{hist, i, tpos, nullptr, &s_np, i + 1};
         uint8_t rf = rep_flags_wave(ch, i + 1, cur.key, lane);
         cur.flags = (uint8_t)((cur.flags & F_IRREV) | rf);
         __syncthreads();
@@ -696,9 +812,7 @@ __global__ __launch_bounds__(64) void k_set_position(SpParams p, int g, const ui
         tpos[0] = cur;
         p.N[nb] = 0;
         p.W[nb] = 0.0f;
-        p.NC[nb] = 0;
-        p.FC[nb] = -1;
-        p.PS[nb] = 0;
+        p.H[nb] = NodeHdr{-1, 0, 0};
         c.ply = n_moves;
         c.start_ply = n_moves;
         c.sim = 0;
@@ -747,7 +861,7 @@ __global__ __launch_bounds__(64) void k_encode_positions(int n_pos, const uint16
         make_move(cur, mv[i]);
         if (lane == 0) s_np = cur;
         __syncthreads();
-        DevChain ch{hist, i, hist, nullptr, nullptr, &s_np, i + 1};
+        DevChain ch{hist, i, hist, nullptr, &s_np, i + 1};
         uint8_t rf = rep_flags_wave(ch, i + 1, cur.key, lane);
         cur.flags = (uint8_t)((cur.flags & F_IRREV) | rf);
         __syncthreads();
@@ -770,7 +884,10 @@ __global__ __launch_bounds__(64) void k_encode_positions(int n_pos, const uint16
         int32_t mtmp_dummy[8];
         (void)mtmp_dummy;
         __shared__ int32_t s_meta[8];
-        encode_wave(hc, played, lane, s_stage, boards + (size_t)g * 7168, s_meta);
+        __shared__ Position s_hist[8];
+        stage_history(hc, played, lane, s_hist);
+        __syncthreads();
+        encode_wave(s_hist, played < 7 ? played + 1 : 8, lane, s_stage, boards + (size_t)g * 7168, s_meta);
         __syncthreads();
         if (meta && lane < 7) meta[(size_t)g * 7 + lane] = s_meta[lane];
     } else if (meta && lane == 0) {

@@ -22,6 +22,14 @@ struct GameCtl {
     int32_t pad;
 };
 
+// per-node header, fetched in one 8-byte load (and, for all children of a node, in the same round trip as their
+// statistics, so that a descent costs one dependent memory round trip per level)
+struct NodeHdr {
+    int32_t fc;   // >=0 first child; -1 unexpanded; -2/-3/-4 terminal with value 0/+1/-1
+    uint16_t nc;  // number of children
+    uint16_t ps;  // tpos slot of an expanded node
+};
+
 struct TraceHdr {
     int32_t n_steps, has_outcome, termination, winner;
     uint64_t game_id;
@@ -47,9 +55,7 @@ struct SpParams {
     float* P;
     float* U;
     uint16_t* MV;
-    uint16_t* NC;
-    int32_t* FC;      // >=0 first child; -1 unexpanded; -2/-3/-4 terminal with value 0/+1/-1
-    uint16_t* PS;     // tpos slot of an expanded node
+    NodeHdr* H;
     int8_t* boards;   // [slot][7168]
     int32_t* meta;    // [slot][8]
     uint16_t* legal_mv;   // [slot][MAXC]
@@ -72,6 +78,7 @@ struct SpParams {
     const float* vpart;
     const float* vf_w;
     uint32_t vf_fc1b, vf_fc1m, vf_fc2w, vf_fc2b;
+    unsigned long long* dbg_cycles;  // optional [slot][8] cycle stamps of the last k_mcts launch (developer aid)
 };
 
 

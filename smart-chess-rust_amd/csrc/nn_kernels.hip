@@ -11,16 +11,19 @@ namespace scl {
 size_t tower_lds_bytes(int C) {
     size_t cp = (size_t)C + 16, hp = scnn::HEAD + 16, rp = (size_t)C + 4;
     size_t rs = std::max<size_t>(64 * rp * 4, 64 * hp * 2);
-    return 100 * cp * 2 + rs + 512 * 4 + 640 * 4 + 8 * 4 + 4 * 64 * 8;
+    return 100 * cp * 2 + rs + 1024 * 4 + 768 * 4 + 8 * 4 + 4 * 64 * 8;
 }
 const char* nn_init() {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scnn::k_tower<256, 4>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scnn::k_tower<256, 4, 1>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)tower_lds_bytes(256));
     if (e != hipSuccess) return hipGetErrorString(e);
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scnn::k_tower<256, 8>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scnn::k_tower<256, 8, 1>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)tower_lds_bytes(256));
     if (e != hipSuccess) return hipGetErrorString(e);
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scnn::k_tower<128, 4>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scnn::k_tower<128, 4, 1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)tower_lds_bytes(128));
+    if (e != hipSuccess) return hipGetErrorString(e);
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scnn::k_tower<128, 12, 3>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)tower_lds_bytes(128));
     if (e != hipSuccess) return hipGetErrorString(e);
     return nullptr;
@@ -31,12 +34,16 @@ void tower(const scnn::TowerArgs& a, hipStream_t s) {
     static const int stagger = getenv("SC_TOWER_STAGGER") ? atoi(getenv("SC_TOWER_STAGGER")) : 0;
     scnn::TowerArgs b = a;
     b.stagger = stagger;
+    static const int delay = getenv("SC_TOWER_DELAY") ? atoi(getenv("SC_TOWER_DELAY")) : 0;
+    b.delay = delay;
     if (a.net.C == 256 && ring == 8)
-        hipLaunchKernelGGL((scnn::k_tower<256, 8>), dim3(a.n_pos), dim3(256), tower_lds_bytes(256), s, b);
+        hipLaunchKernelGGL((scnn::k_tower<256, 8, 1>), dim3(a.n_pos), dim3(256), tower_lds_bytes(256), s, b);
     else if (a.net.C == 256)
-        hipLaunchKernelGGL((scnn::k_tower<256, 4>), dim3(a.n_pos), dim3(256), tower_lds_bytes(256), s, b);
+        hipLaunchKernelGGL((scnn::k_tower<256, 4, 1>), dim3(a.n_pos), dim3(256), tower_lds_bytes(256), s, b);
+    else if (ring == 12)
+        hipLaunchKernelGGL((scnn::k_tower<128, 12, 3>), dim3(a.n_pos), dim3(256), tower_lds_bytes(128), s, b);
     else
-        hipLaunchKernelGGL((scnn::k_tower<128, 4>), dim3(a.n_pos), dim3(256), tower_lds_bytes(128), s, b);
+        hipLaunchKernelGGL((scnn::k_tower<128, 4, 1>), dim3(a.n_pos), dim3(256), tower_lds_bytes(128), s, b);
 }
 void value_fc1(const scnn::Fc1Args& a, hipStream_t s) {
     if (a.n_pos <= 0) return;

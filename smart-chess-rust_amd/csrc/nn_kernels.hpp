@@ -69,14 +69,20 @@ __device__ __forceinline__ bf16x8 wload(__amdgpu_buffer_rsrc_t rsrc, int voff, i
     return __builtin_bit_cast(bf16x8, v);
 }
 
-// xoff: byte offset of the image inside g_smem.  RS: weight ring slots (prefetch distance RS-1 k-steps).
-// t0: first tap (taps are processed cyclically from t0; 0 = natural order).
-template <int CIN, int TAPS, int NTW, int NT_TOTAL, bool HALO, int CP, int RS>
+// xoff: byte offset of the image inside g_smem.
+// RS: weight ring slots (prefetch distance RS-1 k-steps).  TPI: taps per loop iteration; one iteration covers
+// SPG = TPI*KPT k-steps, fully unrolled, and RS divides SPG (RS <= KPT with TPI = 1, or RS = SPG for the narrow
+// trunk whose 4-step taps would otherwise cap the prefetch distance at 3 steps = 384 MFMA cycles, less than the
+// L2 latency under load).  t0: first tap group (groups are processed cyclically from t0; 0 = natural order).
+template <int CIN, int TAPS, int NTW, int NT_TOTAL, bool HALO, int CP, int RS, int TPI>
 __device__ __forceinline__ void conv_mma(int xoff, const bf16_t* __restrict__ Wp, int wave_u, int lane, int t0,
                                          f32x4 (&acc)[4][NTW]) {
     constexpr int KPT = CIN / 32;          // k-steps per tap
+    constexpr int SPG = KPT * TPI;         // k-steps per loop iteration (tap group)
+    constexpr int NG = TAPS / TPI;         // tap groups
     constexpr int SBB = NT_TOTAL * 1024;   // bytes per k-step of packed weights
-    static_assert(KPT % RS == 0 && (RS == 4 || RS == 8), "k-steps per tap must be a multiple of the ring size");
+    constexpr int PD = RS - 1;             // prefetch distance
+    static_assert(TAPS % TPI == 0 && SPG % RS == 0 && PD < SPG, "bad ring / tap-group geometry");
     const int row16 = lane & 15, kq = lane >> 4;
     // LDS byte offsets of this lane's 4 A rows at the centre tap; tap offsets are scalars, k offsets immediates
     int pa[4];
@@ -91,44 +97,49 @@ __device__ __forceinline__ void conv_mma(int xoff, const bf16_t* __restrict__ Wp
     auto toffb = [](int t) { return (TAPS == 9) ? ((((t * 11) >> 5) - 1) * 10 + (t - 3 * ((t * 11) >> 5)) - 1) * CP * 2 : 0; };
     // B: ring of RS register slots, loads run RS-1 k-steps ahead of the MFMAs that consume them (the slot being
     // refilled was consumed one step earlier).  A: double-buffered LDS fragments, one step ahead.  Prefetches
-    // past the last tap wrap to the first one (valid memory, values unused).
+    // past the last group wrap to the first one (valid memory, values unused).
     bf16x8 bq[RS][NTW];
     bf16x8 aq[2][4];
-    int t = t0;
-    int wcur = t * (KPT * SBB);
-    int pc[4];
+    int tg = t0;
+    int wcur = tg * (SPG * SBB);
+    int pc[TPI][4];
 #pragma unroll
-    for (int mt = 0; mt < 4; mt++) pc[mt] = pa[mt] + toffb(t);
+    for (int tl = 0; tl < TPI; tl++)
 #pragma unroll
-    for (int st = 0; st < RS - 1; st++)
+        for (int mt = 0; mt < 4; mt++) pc[tl][mt] = pa[mt] + toffb(tg * TPI + tl);
+#pragma unroll
+    for (int st = 0; st < PD; st++)
 #pragma unroll
         for (int i = 0; i < NTW; i++) bq[st][i] = wload(rsrc, voff + i * 1024, wcur + st * SBB);
 #pragma unroll
-    for (int mt = 0; mt < 4; mt++) aq[0][mt] = lds_frag(pc[mt]);
+    for (int mt = 0; mt < 4; mt++) aq[0][mt] = lds_frag(pc[0][mt]);
 #pragma unroll 1
-    for (int j = 0; j < TAPS; j++) {
-        int tn = t + 1;
-        if (tn == TAPS) tn = 0;
-        const int wnext = tn * (KPT * SBB);
-        int pn[4];
+    for (int j = 0; j < NG; j++) {
+        int tn = tg + 1;
+        if (tn == NG) tn = 0;
+        const int wnext = tn * (SPG * SBB);
+        int pn[TPI][4];
 #pragma unroll
-        for (int mt = 0; mt < 4; mt++) pn[mt] = pa[mt] + toffb(tn);
+        for (int tl = 0; tl < TPI; tl++)
 #pragma unroll
-        for (int kc = 0; kc < KPT; kc++) {
-            const int u = kc % RS;
-            constexpr int PD = RS - 1;
+            for (int mt = 0; mt < 4; mt++) pn[tl][mt] = pa[mt] + toffb(tn * TPI + tl);
+#pragma unroll
+        for (int u = 0; u < SPG; u++) {
+            constexpr int dummy = 0;
+            (void)dummy;
+            const int slot = u % RS;
 #pragma unroll
             for (int i = 0; i < NTW; i++)
-                bq[(u + PD) % RS][i] = (kc + PD < KPT) ? wload(rsrc, voff + i * 1024, wcur + (kc + PD) * SBB)
-                                                       : wload(rsrc, voff + i * 1024, wnext + (kc + PD - KPT) * SBB);
+                bq[(slot + PD) % RS][i] = (u + PD < SPG) ? wload(rsrc, voff + i * 1024, wcur + (u + PD) * SBB)
+                                                         : wload(rsrc, voff + i * 1024, wnext + (u + PD - SPG) * SBB);
 #pragma unroll
             for (int mt = 0; mt < 4; mt++)
-                aq[(kc + 1) & 1][mt] = (kc + 1 < KPT) ? lds_frag(pc[mt] + (kc + 1) * 64) : lds_frag(pn[mt]);
+                aq[(u + 1) & 1][mt] = (u + 1 < SPG) ? lds_frag(pc[(u + 1) / KPT][mt] + ((u + 1) % KPT) * 64) : lds_frag(pn[0][mt]);
 #pragma unroll
             for (int mt = 0; mt < 4; mt++)
 #pragma unroll
                 for (int i = 0; i < NTW; i++)
-                    acc[mt][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[kc & 1][mt], bq[u][i], acc[mt][i], 0, 0, 0);
+                    acc[mt][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[u & 1][mt], bq[slot][i], acc[mt][i], 0, 0, 0);
             // Issue order inside the step: one m-tile of MFMAs, then one LDS read and one weight load, ... so the
             // matrix pipe never waits behind a burst of 8 memory instructions; the fence keeps every prefetch in
             // the step it was written in (otherwise the scheduler sinks loads to just before their use and the
@@ -141,30 +152,40 @@ __device__ __forceinline__ void conv_mma(int xoff, const bf16_t* __restrict__ Wp
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        t = tn;
+        tg = tn;
         wcur = wnext;
 #pragma unroll
-        for (int mt = 0; mt < 4; mt++) pc[mt] = pn[mt];
+        for (int tl = 0; tl < TPI; tl++)
+#pragma unroll
+            for (int mt = 0; mt < 4; mt++) pc[tl][mt] = pn[tl][mt];
     }
 }
 
-// 1 x K vector times packed B (K x 16*NTW*4): the vector sits in row 0 of the A tile.
+// 1 x K vector times packed B: the vector sits in row 0 of the A tile.  The weight fragments are fetched by
+// vec_w_load (early, so that the L2 round trip hides under other epilogue work) and consumed by vec_mma.
 // x: LDS floats (rounded to bf16 on load).  Result for column tile i: lanes 0..15, element 0.
+template <int K, int NTW>
+struct VecW {
+    bf16x8 w[K / 32][NTW];
+};
 template <int K, int NTW, int NT_TOTAL>
-__device__ inline void vec_mma(const float* x, const bf16_t* __restrict__ Wp, int wave, int lane, f32x4 (&acc)[NTW]) {
-    constexpr int S = K / 32;
-    const int row16 = lane & 15, kq = lane >> 4;
-    const bf16x8* __restrict__ Wv = reinterpret_cast<const bf16x8*>(Wp) + (size_t)(wave * NTW) * 64 + lane;
+__device__ __forceinline__ void vec_w_load(VecW<K, NTW>& v, const bf16_t* __restrict__ Wp, int tile0, int lane) {
+    const bf16x8* __restrict__ Wv = reinterpret_cast<const bf16x8*>(Wp) + (size_t)tile0 * 64 + lane;
 #pragma unroll
-    for (int s = 0; s < S; s++) {
+    for (int s = 0; s < K / 32; s++)
+#pragma unroll
+        for (int i = 0; i < NTW; i++) v.w[s][i] = Wv[((size_t)s * NT_TOTAL + i) * 64];
+}
+template <int K, int NTW>
+__device__ __forceinline__ void vec_mma(const float* x, const VecW<K, NTW>& v, int lane, f32x4 (&acc)[NTW]) {
+    const int row16 = lane & 15, kq = lane >> 4;
+#pragma unroll
+    for (int s = 0; s < K / 32; s++) {
         bf16x8 a;
 #pragma unroll
         for (int j = 0; j < 8; j++) a[j] = (__bf16)(row16 == 0 ? x[s * 32 + 8 * kq + j] : 0.0f);
 #pragma unroll
-        for (int i = 0; i < NTW; i++) {
-            bf16x8 b = Wv[((size_t)s * NT_TOTAL + i) * 64];
-            acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[i], 0, 0, 0);
-        }
+        for (int i = 0; i < NTW; i++) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, v.w[s][i], acc[i], 0, 0, 0);
     }
 }
 
@@ -181,8 +202,12 @@ __device__ inline int chan0(int wave, int lane) { return wave * (16 * NTW) + (la
 // per statistic instead of 64, and lane c of each group ends up owning row t = c of its group's 16 rows.
 template <int NTW>
 __device__ inline void bias_layernorm(f32x4 (&acc)[4][NTW], const float* __restrict__ bias, const float* __restrict__ gamma,
-                                      const float* __restrict__ beta, int count, bool relu, int wave, int lane, float* s_stat,
-                                      float* s_mr) {
+                                      const float* __restrict__ beta, int count, bool relu, int wave, int lane, float* s_stat2,
+                                      float* s_mr, int& parity) {
+    // two alternating partial-sum buffers: the buffer written here was last read two LayerNorms ago, and every
+    // wave has passed the barrier of the LayerNorm in between since then -> one barrier per LayerNorm suffices
+    float* s_stat = s_stat2 + (parity & 1) * 512;
+    parity ^= 1;
     const int c0 = chan0<NTW>(wave, lane);
     float bv[NTW], gv[NTW], ev[NTW];
 #pragma unroll
@@ -220,7 +245,6 @@ __device__ inline void bias_layernorm(f32x4 (&acc)[4][NTW], const float* __restr
     }
     const int t_own = lane & 15;
     const int row_own = (t_own >> 2) * 16 + (lane >> 4) * 4 + (t_own & 3);
-    __syncthreads();  // previous users of s_stat are done
     reinterpret_cast<float2*>(s_stat)[row_own * 4 + wave] = make_float2(sm[0], sq[0]);
     __syncthreads();
     {
@@ -273,7 +297,7 @@ __device__ inline void store_image(const f32x4 (&acc)[4][NTW], bf16_t* X, int wa
 }
 
 
-template <int C, int RS>
+template <int C, int RS, int TPI>
 __global__ __launch_bounds__(256, 1) void k_tower(TowerArgs A) {
     constexpr int NTW = C / 64;        // column tiles per wave in the trunk (4 or 2)
     constexpr int NT = C / 16;
@@ -287,8 +311,8 @@ __global__ __launch_bounds__(256, 1) void k_tower(TowerArgs A) {
     float* Rs = reinterpret_cast<float*>(smem + XA_BYTES);                  // [64][RP] fp32 residual stream (trunk)
     bf16_t* Xh = reinterpret_cast<bf16_t*>(smem + XA_BYTES);                // [64][HP] policy hidden; aliases Rs (heads only)
     float* s_stat = reinterpret_cast<float*>(smem + XA_BYTES + RS_BYTES);   // [64][4][2]
-    float* s_vec = s_stat + 512;                                            // pooled[256] | hidden[128] | scale[256]
-    float* s_red = s_vec + 640;                                             // [8]
+    float* s_vec = s_stat + 1024;                                           // pooled[256] | hidden: 4 waves x [128]
+    float* s_red = s_vec + 768;                                             // [8]
     float* s_mr = s_red + 8;                                                // [4 waves][64] (mean, rstd)
     float* s_z = reinterpret_cast<float*>(smem);                            // policy logits [4672], aliases Xa (after the trunk)
     static_assert(4672 * 4 <= XA_BYTES, "policy logits must fit in the image area");
@@ -299,6 +323,12 @@ __global__ __launch_bounds__(256, 1) void k_tower(TowerArgs A) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform: scalar addressing of the weights
     const NetDev& net = A.net;
 
+    // de-phase the workgroups: all of them stream the same weights, offsetting them in time by a fraction of a
+    // layer spreads their L2 requests over different lines/channels without changing any summation order
+    if (A.delay > 0) {
+        const int n = ((int)(blockIdx.x % 9u) * A.delay) >> 6;
+        for (int i = 0; i < n; i++) __builtin_amdgcn_s_sleep(1);
+    }
     // ---- zero the image (halo stays zero for the whole kernel), then load the 112 input planes
     {
         uint4* z = reinterpret_cast<uint4*>(Xa);
@@ -324,6 +354,7 @@ __global__ __launch_bounds__(256, 1) void k_tower(TowerArgs A) {
     // The fp32 residual stream is parked in LDS between blocks (160 KiB/CU and one workgroup per CU make
     // that free) so that the conv loops keep only accumulators + operand rings in registers.
     f32x4 acc[4][NTW];
+    int ln_parity = 0;
     auto store_res = [&]() {
         const int c0 = chan0<NTW>(wave, lane);
 #pragma unroll
@@ -346,11 +377,13 @@ __global__ __launch_bounds__(256, 1) void k_tower(TowerArgs A) {
 
     // ---- conv_block (py/module.py:120-126): conv3x3 112->C (K padded to 128/tap), LN, ReLU
     zero_acc();
-    const int t0 = A.stagger ? (int)((blockIdx.x * (unsigned)A.stagger) % 9u) : 0;
-    conv_mma<128, 9, NTW, NT, true, CP, 4>(0, net.wb + net.o_stem, wave, lane, t0, acc);
+    // stem: K = 9 taps x 128 padded input planes (4 k-steps per tap)
+    constexpr int SRS = (TPI > 1) ? 4 * TPI : 4;
+    const int t0 = A.stagger ? (int)((blockIdx.x * (unsigned)A.stagger) % (unsigned)(9 / TPI)) : 0;
+    conv_mma<128, 9, NTW, NT, true, CP, SRS, TPI>(0, net.wb + net.o_stem, wave, lane, t0, acc);
     {
         const float* f = net.wf + net.f_stem;
-        bias_layernorm<NTW>(acc, f, f + C, f + 2 * C, C, true, wave, lane, s_stat, s_mr);
+        bias_layernorm<NTW>(acc, f, f + C, f + 2 * C, C, true, wave, lane, s_stat, s_mr, ln_parity);
     }
     store_res();
     store_image<NTW, true, CP>(acc, Xa, wave, lane);  // every wave passed the LN barriers: the input image is dead
@@ -376,15 +409,23 @@ __global__ __launch_bounds__(256, 1) void k_tower(TowerArgs A) {
         const float* wf = net.wf + net.f_blocks + (size_t)b * net.blk_stride_f;
         // conv1 -> LN -> ReLU
         zero_acc();
-        conv_mma<C, 9, NTW, NT, true, CP, RS>(0, wb, wave, lane, t0, acc);
-        bias_layernorm<NTW>(acc, wf, wf + C, wf + 2 * C, C, true, wave, lane, s_stat, s_mr);
+        conv_mma<C, 9, NTW, NT, true, CP, RS, TPI>(0, wb, wave, lane, t0, acc);
+        bias_layernorm<NTW>(acc, wf, wf + C, wf + 2 * C, C, true, wave, lane, s_stat, s_mr, ln_parity);
         store_image<NTW, true, CP>(acc, Xa, wave, lane);
         __syncthreads();
         // conv2 -> LN
         zero_acc();
-        conv_mma<C, 9, NTW, NT, true, CP, RS>(0, wb + (size_t)9 * C * C, wave, lane, t0, acc);
-        bias_layernorm<NTW>(acc, wf + 3 * C, wf + 4 * C, wf + 5 * C, C, false, wave, lane, s_stat, s_mr);
-        // squeeze-excitation: global average pool over the 64 pixels
+        conv_mma<C, 9, NTW, NT, true, CP, RS, TPI>(0, wb + (size_t)9 * C * C, wave, lane, t0, acc);
+        // squeeze-excitation weights are requested now: their L2 round trip hides under the LayerNorm below.
+        // Narrow trunk: every wave computes the whole C -> C/2 layer itself (16 fragments), which removes the
+        // hidden-vector exchange and its barrier; wide trunk: the columns are split over the 4 waves.
+        constexpr int NT1 = C / 32;                       // column tiles of fc1
+        constexpr bool FULL1 = (C == 128);
+        constexpr int NTW1 = FULL1 ? NT1 : NT1 / 4;
+        VecW<C, NTW1> w1;
+        vec_w_load<C, NTW1, NT1>(w1, wb + (size_t)18 * C * C, FULL1 ? 0 : wave * NTW1, lane);
+        bias_layernorm<NTW>(acc, wf + 3 * C, wf + 4 * C, wf + 5 * C, C, false, wave, lane, s_stat, s_mr, ln_parity);
+        // global average pool over the 64 pixels
         {
             float cs[NTW];
 #pragma unroll
@@ -404,47 +445,47 @@ __global__ __launch_bounds__(256, 1) void k_tower(TowerArgs A) {
                 for (int i = 0; i < NTW; i++) s_vec[c0 + i] = cs[i];
             }
         }
+        VecW<C / 2, NTW> w2;
+        vec_w_load<C / 2, NTW, NT>(w2, wb + (size_t)18 * C * C + (size_t)C * (C / 2), wave * NTW, lane);
         __syncthreads();
+        float* s_hid = s_vec + 256 + (FULL1 ? wave * 128 : 0);   // hidden vector (wave-private when FULL1)
         {
-            // fc1: C -> C/2, ReLU   (columns split over the 4 waves: C/2/16/4 tiles each)
-            constexpr int NT1 = C / 32, NTW1 = NT1 / 4;
+            // fc1: C -> C/2, ReLU
             f32x4 h[NTW1];
 #pragma unroll
             for (int i = 0; i < NTW1; i++) h[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-            vec_mma<C, NTW1, NT1>(s_vec, wb + (size_t)18 * C * C, wave, lane, h);
+            vec_mma<C, NTW1>(s_vec, w1, lane, h);
             const float* b1 = wf + 6 * C;
             if (lane < 16) {
-                const int j0 = chan0<NTW1>(wave, lane);
 #pragma unroll
                 for (int i = 0; i < NTW1; i++) {
-                    float v = h[i][0] + b1[j0 + i];
-                    s_vec[256 + j0 + i] = v > 0.f ? v : 0.f;
+                    // packed column (tile, lane) -> hidden channel: tiles were laid out for a 4-wave split
+                    constexpr int PW = NT1 / 4;  // tiles per wave in the packed order
+                    const int tile = FULL1 ? i : wave * NTW1 + i;
+                    const int j = (tile / PW) * (16 * PW) + (lane & 15) * PW + (tile % PW);
+                    float v = h[i][0] + b1[j];
+                    s_hid[j] = v > 0.f ? v : 0.f;
                 }
             }
         }
-        __syncthreads();
+        if (!FULL1) __syncthreads();  // FULL1: the hidden vector is wave-private (DS ops of a wave execute in order)
+        float scl[NTW];
         {
-            // fc2: C/2 -> C, sigmoid
+            // fc2: C/2 -> C, sigmoid; every wave produces the scales of exactly its own channels
             f32x4 sc[NTW];
 #pragma unroll
             for (int i = 0; i < NTW; i++) sc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-            vec_mma<C / 2, NTW, NT>(s_vec + 256, wb + (size_t)18 * C * C + (size_t)C * (C / 2), wave, lane, sc);
+            vec_mma<C / 2, NTW>(s_hid, w2, lane, sc);
             const float* b2 = wf + 6 * C + C / 2;
-            if (lane < 16) {
-                const int c0 = chan0<NTW>(wave, lane);
+            const int c0 = chan0<NTW>(wave, lane);
 #pragma unroll
-                for (int i = 0; i < NTW; i++) {
-                    float v = sc[i][0] + b2[c0 + i];
-                    s_vec[384 + c0 + i] = 1.0f / (1.0f + __expf(-v));
-                }
+            for (int i = 0; i < NTW; i++) {
+                float v = 1.0f / (1.0f + __expf(-(sc[i][0] + b2[c0 + i])));  // valid in lanes 0..15
+                scl[i] = __shfl(v, lane & 15, 64);
             }
         }
-        __syncthreads();
         {
             const int c0 = chan0<NTW>(wave, lane);
-            float scl[NTW];
-#pragma unroll
-            for (int i = 0; i < NTW; i++) scl[i] = s_vec[384 + c0 + i];
 #pragma unroll
             for (int mt = 0; mt < 4; mt++)
 #pragma unroll
@@ -479,9 +520,9 @@ __global__ __launch_bounds__(256, 1) void k_tower(TowerArgs A) {
         for (int mt = 0; mt < 4; mt++)
 #pragma unroll
             for (int i = 0; i < 4; i++) hv[mt][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        conv_mma<C, 1, 4, 16, true, CP, RS>(0, net.wb + net.o_vconv, wave, lane, 0, hv);
+        conv_mma<C, 1, 4, 16, true, CP, 4, 1>(0, net.wb + net.o_vconv, wave, lane, 0, hv);
         const float* f = net.wf + net.f_vhead;
-        bias_layernorm<4>(hv, f, f + HEAD, f + 2 * HEAD, HEAD, true, wave, lane, s_stat, s_mr);
+        bias_layernorm<4>(hv, f, f + HEAD, f + 2 * HEAD, HEAD, true, wave, lane, s_stat, s_mr, ln_parity);
         const int c0 = chan0<4>(wave, lane);
 #pragma unroll
         for (int mt = 0; mt < 4; mt++)
@@ -501,9 +542,9 @@ __global__ __launch_bounds__(256, 1) void k_tower(TowerArgs A) {
         for (int mt = 0; mt < 4; mt++)
 #pragma unroll
             for (int i = 0; i < 4; i++) hp[mt][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        conv_mma<C, 1, 4, 16, true, CP, RS>(0, net.wb + net.o_pconv1, wave, lane, 0, hp);
+        conv_mma<C, 1, 4, 16, true, CP, 4, 1>(0, net.wb + net.o_pconv1, wave, lane, 0, hp);
         const float* f = net.wf + net.f_phead1;
-        bias_layernorm<4>(hp, f, f + HEAD, f + 2 * HEAD, HEAD, false, wave, lane, s_stat, s_mr);
+        bias_layernorm<4>(hp, f, f + HEAD, f + 2 * HEAD, HEAD, false, wave, lane, s_stat, s_mr, ln_parity);
         store_image<4, false, HP>(hp, Xh, wave, lane);
     }
     __syncthreads();
@@ -513,10 +554,10 @@ __global__ __launch_bounds__(256, 1) void k_tower(TowerArgs A) {
         for (int mt = 0; mt < 4; mt++)
 #pragma unroll
             for (int i = 0; i < 2; i++) z[mt][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        conv_mma<HEAD, 1, 2, 8, false, HP, 4>(XA_BYTES, net.wb + net.o_pconv2, wave, lane, 0, z);
+        conv_mma<HEAD, 1, 2, 8, false, HP, 4, 1>(XA_BYTES, net.wb + net.o_pconv2, wave, lane, 0, z);
         const float* f = net.wf + net.f_phead2;
         // padded channels (>=73) have zero weights, bias, gamma, beta: they add 0 to both LN sums
-        bias_layernorm<2>(z, f, f + POL_PAD, f + 2 * POL_PAD, 73, false, wave, lane, s_stat, s_mr);
+        bias_layernorm<2>(z, f, f + POL_PAD, f + 2 * POL_PAD, 73, false, wave, lane, s_stat, s_mr, ln_parity);
         __syncthreads();  // everyone is done with Xa/Xh: the logits may overwrite the image area
         const int c0 = chan0<2>(wave, lane);
 #pragma unroll
@@ -586,15 +627,27 @@ __global__ __launch_bounds__(256) void k_value_fc1(Fc1Args A) {
     for (int mt = 0; mt < 4; mt++)
 #pragma unroll
         for (int i = 0; i < 2; i++) acc[mt][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int s = 0; s < steps; s++) {
-        bf16x8 b0 = Wv[((size_t)s * 8 + 0) * 64], b1 = Wv[((size_t)s * 8 + 1) * 64];
-        bf16x8 a[4];
+    // the kernel is a short dependent chain per workgroup: issue the operand loads of 8 k-steps at a time so
+    // that 48 loads are in flight before the first MFMA (this kernel is latency-, not bandwidth-bound)
+    for (int s0 = 0; s0 < steps; s0 += 8) {
+        bf16x8 bb[8][2], aa[8][4];
 #pragma unroll
-        for (int mt = 0; mt < 4; mt++) a[mt] = *reinterpret_cast<const bf16x8*>(arow[mt] + s * 32);
+        for (int u = 0; u < 8; u++) {
+            const int s = s0 + u < steps ? s0 + u : steps - 1;
+            bb[u][0] = Wv[((size_t)s * 8 + 0) * 64];
+            bb[u][1] = Wv[((size_t)s * 8 + 1) * 64];
 #pragma unroll
-        for (int mt = 0; mt < 4; mt++) {
-            acc[mt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt], b0, acc[mt][0], 0, 0, 0);
-            acc[mt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt], b1, acc[mt][1], 0, 0, 0);
+            for (int mt = 0; mt < 4; mt++) aa[u][mt] = *reinterpret_cast<const bf16x8*>(arow[mt] + s * 32);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            if (s0 + u < steps) {
+#pragma unroll
+                for (int mt = 0; mt < 4; mt++) {
+                    acc[mt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aa[u][mt], bb[u][0], acc[mt][0], 0, 0, 0);
+                    acc[mt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aa[u][mt], bb[u][1], acc[mt][1], 0, 0, 0);
+                }
+            }
         }
     }
     const int c0 = chan0<2>(wave, lane);

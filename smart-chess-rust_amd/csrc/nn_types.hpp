@@ -33,6 +33,7 @@ struct TowerArgs {
     float* dbg;                 // optional: [n][64][C] residual stream dump
     int dbg_stage;              // -1: none; 0: after stem; b>=1: after block b; 1000: final latent
     int stagger;                // experiment: workgroup b starts the 3x3 taps at (b*stagger)%9 (0 = natural order)
+    int delay;                  // workgroup b sleeps (b%9)*delay cycles first: de-phases the workgroups' weight streams
 };
 
 struct Fc1Args {

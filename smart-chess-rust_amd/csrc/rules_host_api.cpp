@@ -140,6 +140,7 @@ void sct_encode(const sct_state* s, int8_t* boards, int32_t* meta) {
 int sct_move_index(uint16_t m, int turn) { return move_index(m, turn); }
 uint64_t sct_pos_hash(const sct_state* s) { return synth_pos_hash(s->hist.back()); }
 uint64_t sct_key(const sct_state* s) { return s->hist.back().key; }
+uint64_t sct_key_full(const sct_state* s) { return position_key(s->hist.back()); }
 uint64_t sct_rng(uint64_t a, uint64_t b, uint64_t c, uint64_t d, uint64_t e) { return sc_rng(a, b, c, d, e); }
 void sct_synth_eval(const sct_state* s, float* priors, float* value) {
     move_t buf[MAX_MOVES];

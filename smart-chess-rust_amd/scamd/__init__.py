@@ -12,5 +12,6 @@ reference's usage:
 There is NO CPU fallback: importing works anywhere (so the C ABI can be checked), but every
 compute entry point raises EngineError when the HIP library or a GPU is missing.
 """
-from .binding import (ChessHip, Engine, EngineError, SelfPlay, encode_positions, lib, lib_path, move_uci,  # noqa: F401
-                      uci_move, write_trace_json, TERMINATION)
+from .binding import (ChessHip, Engine, EngineError, SelfPlay, encode_positions, enqueue_interleaved, lib, lib_path,  # noqa: F401
+                      move_uci, uci_move, write_trace_json, TERMINATION)
+from . import binding  # noqa: F401

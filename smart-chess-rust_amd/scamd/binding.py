@@ -26,7 +26,7 @@ class SelfplayConfig(C.Structure):
                 ("cpuct", C.c_float), ("temperature", C.c_float), ("temperature_switch", C.c_int32),
                 ("epsilon", C.c_float), ("with_noise", C.c_int32), ("outcome_gate", C.c_int32),
                 ("evaluator", C.c_int32), ("external_noise", C.c_int32), ("seed", C.c_uint64),
-                ("first_game_id", C.c_uint64), ("trace_capacity", C.c_int32), ("reserved", C.c_int32)]
+                ("first_game_id", C.c_uint64), ("trace_capacity", C.c_int32), ("own_stream", C.c_int32)]
 
 
 class Stats(C.Structure):
@@ -57,6 +57,7 @@ ABI = {
     "sc_selfplay_destroy": (None, [_vp]),
     "sc_selfplay_enqueue_sims": (_i, [_vp, _i]),
     "sc_selfplay_synchronize": (_i, [_vp]),
+    "sc_selfplay_enqueue_interleaved": (_i, [_vp, _i, _i]),
     "sc_selfplay_run": (_i, [_vp, _i64]),
     "sc_selfplay_get_stats": (_i, [_vp, C.POINTER(Stats)]),
     "sc_selfplay_enable_timing": (_i, [_vp, _i]),
@@ -238,12 +239,12 @@ class SelfPlay:
 
     def __init__(self, engine=None, n_slots=256, n_games=None, rollout_num=180, num_steps=150, cpuct=2.5,
                  temperature=0.0, temperature_switch=4, epsilon=0.15, with_noise=True, outcome_gate=100,
-                 evaluator="net", external_noise=False, seed=0, first_game_id=0, trace_capacity=0, device=0):
+                 evaluator="net", external_noise=False, seed=0, first_game_id=0, trace_capacity=0, own_stream=False, device=0):
         self.L = lib()
         self.engine = engine
         cfg = SelfplayConfig(n_slots, n_games if n_games is not None else n_slots, rollout_num, num_steps, cpuct,
                              temperature, temperature_switch, epsilon, int(with_noise), outcome_gate,
-                             0 if evaluator == "net" else 1, int(external_noise), seed, first_game_id, trace_capacity, 0)
+                             0 if evaluator == "net" else 1, int(external_noise), seed, first_game_id, trace_capacity, int(own_stream))
         self.cfg = cfg
         h = C.c_void_p()
         _check(self.L.sc_selfplay_create(engine.h if engine else None, device, C.byref(cfg), C.byref(h)))
@@ -344,6 +345,12 @@ class SelfPlay:
         if mv.size == 0:
             mv = np.zeros(1, np.uint16)
         _check(self.L.sc_selfplay_set_position(self.h, slot, _p(mv), len(moves)))
+
+
+def enqueue_interleaved(handles, n_sims):
+    """n simulation steps on several SelfPlay handles (own_stream=True), interleaved step by step"""
+    arr = (C.c_void_p * len(handles))(*[h.h for h in handles])
+    _check(lib().sc_selfplay_enqueue_interleaved(arr, len(handles), n_sims))
 
 
 def write_trace_json(path, trace):

@@ -29,6 +29,10 @@ def H():
     L.sct_perft.restype = C.c_uint64
     L.sct_pos_hash.restype = C.c_uint64
     L.sct_rng.restype = C.c_uint64
+    L.sct_key.restype = C.c_uint64
+    L.sct_key_full.restype = C.c_uint64
+    L.sct_key.argtypes = [C.c_void_p]
+    L.sct_key_full.argtypes = [C.c_void_p]
     L.sct_rng.argtypes = [C.c_uint64] * 5
     for n in ("sct_free", "sct_reset", "sct_push", "sct_pop", "sct_encode", "sct_synth_eval"):
         getattr(L, n).restype = None
@@ -101,6 +105,7 @@ def test_cross_check_against_oracle(H, orc):
                 assert {1: "White", 0: "Black", -1: None}[w.value] == oo["winner"]
                 seen_terms.add(oo["termination"])
             assert H.sct_pos_hash(s) == o.pos_hash()
+            assert H.sct_key(s) == H.sct_key_full(s)      # incremental transposition key == full recompute
             for mv in mine:
                 assert H.sct_move_index(mv, o.turn) == orc.move_index(mv, o.turn) >= 0
             n_pos += 1
