@@ -17,9 +17,6 @@ const char* nn_init() {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scnn::k_tower<256, 4, 1>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)tower_lds_bytes(256));
     if (e != hipSuccess) return hipGetErrorString(e);
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scnn::k_tower<256, 8, 1>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)tower_lds_bytes(256));
-    if (e != hipSuccess) return hipGetErrorString(e);
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scnn::k_tower<128, 4, 1>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)tower_lds_bytes(128));
     if (e != hipSuccess) return hipGetErrorString(e);
@@ -36,9 +33,7 @@ void tower(const scnn::TowerArgs& a, hipStream_t s) {
     b.stagger = stagger;
     static const int delay = getenv("SC_TOWER_DELAY") ? atoi(getenv("SC_TOWER_DELAY")) : 0;
     b.delay = delay;
-    if (a.net.C == 256 && ring == 8)
-        hipLaunchKernelGGL((scnn::k_tower<256, 8, 1>), dim3(a.n_pos), dim3(256), tower_lds_bytes(256), s, b);
-    else if (a.net.C == 256)
+    if (a.net.C == 256)
         hipLaunchKernelGGL((scnn::k_tower<256, 4, 1>), dim3(a.n_pos), dim3(256), tower_lds_bytes(256), s, b);
     else if (ring == 12)
         hipLaunchKernelGGL((scnn::k_tower<128, 12, 3>), dim3(a.n_pos), dim3(256), tower_lds_bytes(128), s, b);

@@ -74,9 +74,12 @@ __device__ __forceinline__ bf16x8 wload(__amdgpu_buffer_rsrc_t rsrc, int voff, i
 // SPG = TPI*KPT k-steps, fully unrolled, and RS divides SPG (RS <= KPT with TPI = 1, or RS = SPG for the narrow
 // trunk whose 4-step taps would otherwise cap the prefetch distance at 3 steps = 384 MFMA cycles, less than the
 // L2 latency under load).  t0: first tap group (groups are processed cyclically from t0; 0 = natural order).
-template <int CIN, int TAPS, int NTW, int NT_TOTAL, bool HALO, int CP, int RS, int TPI>
+// Ring carry: `bq` belongs to the caller.  With PRE the first RS-1 slots already hold this layer's first k-steps
+// (the previous layer's loop fetched them: its prefetches past its own last group go to byte offset `next_first`
+// relative to ITS weights, i.e. to the next layer), so a layer starts without an exposed L2 round trip.
+template <int CIN, int TAPS, int NTW, int NT_TOTAL, bool HALO, int CP, int RS, int TPI, bool PRE = false>
 __device__ __forceinline__ void conv_mma(int xoff, const bf16_t* __restrict__ Wp, int wave_u, int lane, int t0,
-                                         f32x4 (&acc)[4][NTW]) {
+                                         f32x4 (&acc)[4][NTW], bf16x8 (&bq)[RS][NTW], int next_first) {
     constexpr int KPT = CIN / 32;          // k-steps per tap
     constexpr int SPG = KPT * TPI;         // k-steps per loop iteration (tap group)
     constexpr int NG = TAPS / TPI;         // tap groups
@@ -98,7 +101,6 @@ __device__ __forceinline__ void conv_mma(int xoff, const bf16_t* __restrict__ Wp
     // B: ring of RS register slots, loads run RS-1 k-steps ahead of the MFMAs that consume them (the slot being
     // refilled was consumed one step earlier).  A: double-buffered LDS fragments, one step ahead.  Prefetches
     // past the last group wrap to the first one (valid memory, values unused).
-    bf16x8 bq[RS][NTW];
     bf16x8 aq[2][4];
     int tg = t0;
     int wcur = tg * (SPG * SBB);
@@ -107,17 +109,19 @@ __device__ __forceinline__ void conv_mma(int xoff, const bf16_t* __restrict__ Wp
     for (int tl = 0; tl < TPI; tl++)
 #pragma unroll
         for (int mt = 0; mt < 4; mt++) pc[tl][mt] = pa[mt] + toffb(tg * TPI + tl);
+    if (!PRE) {
 #pragma unroll
-    for (int st = 0; st < PD; st++)
+        for (int st = 0; st < PD; st++)
 #pragma unroll
-        for (int i = 0; i < NTW; i++) bq[st][i] = wload(rsrc, voff + i * 1024, wcur + st * SBB);
+            for (int i = 0; i < NTW; i++) bq[st][i] = wload(rsrc, voff + i * 1024, wcur + st * SBB);
+    }
 #pragma unroll
     for (int mt = 0; mt < 4; mt++) aq[0][mt] = lds_frag(pc[0][mt]);
 #pragma unroll 1
     for (int j = 0; j < NG; j++) {
         int tn = tg + 1;
         if (tn == NG) tn = 0;
-        const int wnext = tn * (SPG * SBB);
+        const int wnext = (j == NG - 1) ? next_first : tn * (SPG * SBB);
         int pn[TPI][4];
 #pragma unroll
         for (int tl = 0; tl < TPI; tl++)
@@ -176,14 +180,16 @@ __device__ __forceinline__ void vec_w_load(VecW<K, NTW>& v, const bf16_t* __rest
 #pragma unroll
         for (int i = 0; i < NTW; i++) v.w[s][i] = Wv[((size_t)s * NT_TOTAL + i) * 64];
 }
+// x: packed bf16 vector in LDS (16-byte aligned): one ds_read_b128 per k-step instead of 8 scalar reads + converts
 template <int K, int NTW>
-__device__ __forceinline__ void vec_mma(const float* x, const VecW<K, NTW>& v, int lane, f32x4 (&acc)[NTW]) {
+__device__ __forceinline__ void vec_mma(const bf16_t* x, const VecW<K, NTW>& v, int lane, f32x4 (&acc)[NTW]) {
     const int row16 = lane & 15, kq = lane >> 4;
+    typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 #pragma unroll
     for (int s = 0; s < K / 32; s++) {
-        bf16x8 a;
-#pragma unroll
-        for (int j = 0; j < 8; j++) a[j] = (__bf16)(row16 == 0 ? x[s * 32 + 8 * kq + j] : 0.0f);
+        u32x4 raw = *reinterpret_cast<const u32x4*>(x + s * 32 + 8 * kq);
+        if (row16 != 0) raw = u32x4{0u, 0u, 0u, 0u};
+        bf16x8 a = __builtin_bit_cast(bf16x8, raw);
 #pragma unroll
         for (int i = 0; i < NTW; i++) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, v.w[s][i], acc[i], 0, 0, 0);
     }
@@ -200,22 +206,30 @@ __device__ inline int chan0(int wave, int lane) { return wave * (16 * NTW) + (la
 // s_stat: LDS [64 rows][4 waves] float2 partial (sum, sumsq); s_mr: LDS [4 waves][64 rows] float2 (mean, rstd).
 // Row sums over the wave's columns use a halving butterfly over the 16 lanes that share a row group: 15 shuffles
 // per statistic instead of 64, and lane c of each group ends up owning row t = c of its group's 16 rows.
+// The per-channel parameters are fetched by ln_load, which the caller issues a layer EARLY (before the conv that
+// feeds this LayerNorm) so that no epilogue waits on an L2 round trip.
 template <int NTW>
-__device__ inline void bias_layernorm(f32x4 (&acc)[4][NTW], const float* __restrict__ bias, const float* __restrict__ gamma,
-                                      const float* __restrict__ beta, int count, bool relu, int wave, int lane, float* s_stat2,
-                                      float* s_mr, int& parity) {
+struct LnP {
+    float b[NTW], g[NTW], e[NTW];
+};
+template <int NTW>
+__device__ __forceinline__ void ln_load(LnP<NTW>& P, const float* __restrict__ bias, const float* __restrict__ gamma,
+                                        const float* __restrict__ beta, int wave, int lane) {
+    const int c0 = chan0<NTW>(wave, lane);
+#pragma unroll
+    for (int i = 0; i < NTW; i++) {
+        P.b[i] = bias[c0 + i];
+        P.g[i] = gamma[c0 + i];
+        P.e[i] = beta[c0 + i];
+    }
+}
+template <int NTW>
+__device__ inline void bias_layernorm(f32x4 (&acc)[4][NTW], const LnP<NTW>& P, int count, bool relu, int wave, int lane,
+                                      float* s_stat2, float* s_mr, int& parity) {
     // two alternating partial-sum buffers: the buffer written here was last read two LayerNorms ago, and every
     // wave has passed the barrier of the LayerNorm in between since then -> one barrier per LayerNorm suffices
     float* s_stat = s_stat2 + (parity & 1) * 512;
     parity ^= 1;
-    const int c0 = chan0<NTW>(wave, lane);
-    float bv[NTW], gv[NTW], ev[NTW];
-#pragma unroll
-    for (int i = 0; i < NTW; i++) {
-        bv[i] = bias[c0 + i];
-        gv[i] = gamma[c0 + i];
-        ev[i] = beta[c0 + i];
-    }
     float sm[16], sq[16];  // index t = mt*4 + r
 #pragma unroll
     for (int mt = 0; mt < 4; mt++)
@@ -224,7 +238,7 @@ __device__ inline void bias_layernorm(f32x4 (&acc)[4][NTW], const float* __restr
             float s = 0.f, q = 0.f;
 #pragma unroll
             for (int i = 0; i < NTW; i++) {
-                float v = acc[mt][i][r] + bv[i];
+                float v = acc[mt][i][r] + P.b[i];
                 acc[mt][i][r] = v;
                 s += v;
                 q += v * v;
@@ -268,7 +282,7 @@ __device__ inline void bias_layernorm(f32x4 (&acc)[4][NTW], const float* __restr
             float2 mr = reinterpret_cast<const float2*>(s_mr)[wave * 64 + row];
 #pragma unroll
             for (int i = 0; i < NTW; i++) {
-                float y = (acc[mt][i][r] - mr.x) * mr.y * gv[i] + ev[i];
+                float y = (acc[mt][i][r] - mr.x) * mr.y * P.g[i] + P.e[i];
                 acc[mt][i][r] = (relu && y < 0.f) ? 0.f : y;
             }
         }
@@ -314,6 +328,7 @@ __global__ __launch_bounds__(256, 1) void k_tower(TowerArgs A) {
     float* s_vec = s_stat + 1024;                                           // pooled[256] | hidden: 4 waves x [128]
     float* s_red = s_vec + 768;                                             // [8]
     float* s_mr = s_red + 8;                                                // [4 waves][64] (mean, rstd)
+    bf16_t* s_xb = reinterpret_cast<bf16_t*>(s_vec);                        // SE vectors as packed bf16
     float* s_z = reinterpret_cast<float*>(smem);                            // policy logits [4672], aliases Xa (after the trunk)
     static_assert(4672 * 4 <= XA_BYTES, "policy logits must fit in the image area");
 
@@ -379,11 +394,19 @@ __global__ __launch_bounds__(256, 1) void k_tower(TowerArgs A) {
     zero_acc();
     // stem: K = 9 taps x 128 padded input planes (4 k-steps per tap)
     constexpr int SRS = (TPI > 1) ? 4 * TPI : 4;
+    static_assert(SRS == RS, "the stem shares the trunk's weight ring (ring carry across layers)");
     const int t0 = A.stagger ? (int)((blockIdx.x * (unsigned)A.stagger) % (unsigned)(9 / TPI)) : 0;
-    conv_mma<128, 9, NTW, NT, true, CP, SRS, TPI>(0, net.wb + net.o_stem, wave, lane, t0, acc);
+    constexpr int GRP_BYTES = (C / 32) * TPI * NT * 1024;   // bytes of one tap group of a trunk conv
+    bf16x8 ring[RS][NTW];                                  // weight prefetch ring, carried from layer to layer
     {
+        LnP<NTW> P;
         const float* f = net.wf + net.f_stem;
-        bias_layernorm<NTW>(acc, f, f + C, f + 2 * C, C, true, wave, lane, s_stat, s_mr, ln_parity);
+        ln_load<NTW>(P, f, f + C, f + 2 * C, wave, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        const bf16_t* w0 = net.wb + net.o_stem;
+        const int to_blk0 = (int)((net.wb + net.o_blocks) - w0) * 2 + t0 * GRP_BYTES;
+        conv_mma<128, 9, NTW, NT, true, CP, RS, TPI, false>(0, w0, wave, lane, t0, acc, ring, to_blk0);
+        bias_layernorm<NTW>(acc, P, C, true, wave, lane, s_stat, s_mr, ln_parity);
     }
     store_res();
     store_image<NTW, true, CP>(acc, Xa, wave, lane);  // every wave passed the LN barriers: the input image is dead
@@ -402,29 +425,72 @@ __global__ __launch_bounds__(256, 1) void k_tower(TowerArgs A) {
     };
     dump(0);
 
+    // developer aid: dbg_stage 2000 -> cycle stamps (summed over blocks) of the block's phases in dbg[pos][0..7]
+    const bool stamp = A.dbg && A.dbg_stage == 2000 && tid == 0;
+    long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long tprev = 0;
+    auto mark = [&](int k) {
+        if (stamp) {
+            long long t = clock64();
+            tacc[k] += t - tprev;
+            tprev = t;
+        }
+    };
     // ---- residual tower (ResBlockSE.forward, py/module.py:38-46)
 #pragma unroll 1
     for (int b = 0; b < net.n_blocks; b++) {
         const bf16_t* wb = net.wb + net.o_blocks + (size_t)b * net.blk_stride_b;
         const float* wf = net.wf + net.f_blocks + (size_t)b * net.blk_stride_f;
-        // conv1 -> LN -> ReLU
+        // conv1 -> LN -> ReLU.  Per-channel parameters are requested BEFORE the conv that feeds them.
+        if (stamp) tprev = clock64();
+        constexpr int NT1 = C / 32;                       // column tiles of SE fc1
+        constexpr bool FULL1 = (C == 128);
+        constexpr int NTW1 = FULL1 ? NT1 : NT1 / 4;
+        constexpr int PW1 = NT1 / 4;                      // fc1 tiles per wave in the packed column order
+        LnP<NTW> P1, P2;
+        float b1v[NTW1], b2v[NTW];
+        ln_load<NTW>(P1, wf, wf + C, wf + 2 * C, wave, lane);
+        __builtin_amdgcn_sched_barrier(0);
         zero_acc();
-        conv_mma<C, 9, NTW, NT, true, CP, RS, TPI>(0, wb, wave, lane, t0, acc);
-        bias_layernorm<NTW>(acc, wf, wf + C, wf + 2 * C, C, true, wave, lane, s_stat, s_mr, ln_parity);
+        conv_mma<C, 9, NTW, NT, true, CP, RS, TPI, true>(0, wb, wave, lane, t0, acc, ring, 9 * C * C * 2 + t0 * GRP_BYTES);
+        mark(0);
+        ln_load<NTW>(P2, wf + 3 * C, wf + 4 * C, wf + 5 * C, wave, lane);
+        {
+            const float* b1 = wf + 6 * C;
+            const float* b2 = wf + 6 * C + C / 2;
+            const int c0 = chan0<NTW>(wave, lane);
+#pragma unroll
+            for (int i = 0; i < NTW1; i++) {
+                // packed column (tile, lane) -> hidden channel: tiles were laid out for a 4-wave split
+                const int tile = FULL1 ? i : wave * NTW1 + i;
+                b1v[i] = b1[(tile / PW1) * (16 * PW1) + (lane & 15) * PW1 + (tile % PW1)];
+            }
+#pragma unroll
+            for (int i = 0; i < NTW; i++) b2v[i] = b2[c0 + i];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        bias_layernorm<NTW>(acc, P1, C, true, wave, lane, s_stat, s_mr, ln_parity);
         store_image<NTW, true, CP>(acc, Xa, wave, lane);
         __syncthreads();
+        mark(1);
         // conv2 -> LN
         zero_acc();
-        conv_mma<C, 9, NTW, NT, true, CP, RS, TPI>(0, wb + (size_t)9 * C * C, wave, lane, t0, acc);
+        {
+            // the loop's last prefetches fetch the first k-steps of the NEXT block's conv1 (or wrap on the last block)
+            const int nxt = (b + 1 < net.n_blocks) ? (int)(net.blk_stride_b - (size_t)9 * C * C) * 2 + t0 * GRP_BYTES : t0 * GRP_BYTES;
+            conv_mma<C, 9, NTW, NT, true, CP, RS, TPI, true>(0, wb + (size_t)9 * C * C, wave, lane, t0, acc, ring, nxt);
+        }
+        mark(2);
         // squeeze-excitation weights are requested now: their L2 round trip hides under the LayerNorm below.
         // Narrow trunk: every wave computes the whole C -> C/2 layer itself (16 fragments), which removes the
         // hidden-vector exchange and its barrier; wide trunk: the columns are split over the 4 waves.
-        constexpr int NT1 = C / 32;                       // column tiles of fc1
-        constexpr bool FULL1 = (C == 128);
-        constexpr int NTW1 = FULL1 ? NT1 : NT1 / 4;
         VecW<C, NTW1> w1;
         vec_w_load<C, NTW1, NT1>(w1, wb + (size_t)18 * C * C, FULL1 ? 0 : wave * NTW1, lane);
-        bias_layernorm<NTW>(acc, wf + 3 * C, wf + 4 * C, wf + 5 * C, C, false, wave, lane, s_stat, s_mr, ln_parity);
+        VecW<C / 2, NTW> w2;
+        vec_w_load<C / 2, NTW, NT>(w2, wb + (size_t)18 * C * C + (size_t)C * (C / 2), wave * NTW, lane);
+        __builtin_amdgcn_sched_barrier(0);  // keep the loads HERE (the scheduler would sink them to their use)
+        bias_layernorm<NTW>(acc, P2, C, false, wave, lane, s_stat, s_mr, ln_parity);
+        mark(3);
         // global average pool over the 64 pixels
         {
             float cs[NTW];
@@ -442,29 +508,24 @@ __global__ __launch_bounds__(256, 1) void k_tower(TowerArgs A) {
             if (lane < 16) {
                 const int c0 = chan0<NTW>(wave, lane);
 #pragma unroll
-                for (int i = 0; i < NTW; i++) s_vec[c0 + i] = cs[i];
+                for (int i = 0; i < NTW; i++) s_xb[c0 + i] = f2bf(cs[i]);  // conv inputs are bf16 (autocast)
             }
         }
-        VecW<C / 2, NTW> w2;
-        vec_w_load<C / 2, NTW, NT>(w2, wb + (size_t)18 * C * C + (size_t)C * (C / 2), wave * NTW, lane);
         __syncthreads();
-        float* s_hid = s_vec + 256 + (FULL1 ? wave * 128 : 0);   // hidden vector (wave-private when FULL1)
+        bf16_t* s_hid = s_xb + 256 + (FULL1 ? wave * 128 : 0);   // hidden vector (wave-private when FULL1)
         {
             // fc1: C -> C/2, ReLU
             f32x4 h[NTW1];
 #pragma unroll
             for (int i = 0; i < NTW1; i++) h[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-            vec_mma<C, NTW1>(s_vec, w1, lane, h);
-            const float* b1 = wf + 6 * C;
+            vec_mma<C, NTW1>(s_xb, w1, lane, h);
             if (lane < 16) {
 #pragma unroll
                 for (int i = 0; i < NTW1; i++) {
-                    // packed column (tile, lane) -> hidden channel: tiles were laid out for a 4-wave split
-                    constexpr int PW = NT1 / 4;  // tiles per wave in the packed order
                     const int tile = FULL1 ? i : wave * NTW1 + i;
-                    const int j = (tile / PW) * (16 * PW) + (lane & 15) * PW + (tile % PW);
-                    float v = h[i][0] + b1[j];
-                    s_hid[j] = v > 0.f ? v : 0.f;
+                    const int j = (tile / PW1) * (16 * PW1) + (lane & 15) * PW1 + (tile % PW1);
+                    float v = h[i][0] + b1v[i];
+                    s_hid[j] = f2bf(v > 0.f ? v : 0.f);
                 }
             }
         }
@@ -476,14 +537,13 @@ __global__ __launch_bounds__(256, 1) void k_tower(TowerArgs A) {
 #pragma unroll
             for (int i = 0; i < NTW; i++) sc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
             vec_mma<C / 2, NTW>(s_hid, w2, lane, sc);
-            const float* b2 = wf + 6 * C + C / 2;
-            const int c0 = chan0<NTW>(wave, lane);
 #pragma unroll
             for (int i = 0; i < NTW; i++) {
-                float v = 1.0f / (1.0f + __expf(-(sc[i][0] + b2[c0 + i])));  // valid in lanes 0..15
+                float v = 1.0f / (1.0f + __expf(-(sc[i][0] + b2v[i])));  // valid in lanes 0..15
                 scl[i] = __shfl(v, lane & 15, 64);
             }
         }
+        mark(4);
         {
             const int c0 = chan0<NTW>(wave, lane);
 #pragma unroll
@@ -509,9 +569,13 @@ __global__ __launch_bounds__(256, 1) void k_tower(TowerArgs A) {
         store_res();                                      // each lane rewrites exactly the cells it just read
         store_image<NTW, true, CP>(acc, Xa, wave, lane);  // conv2 finished reading Xa before the SE barriers
         __syncthreads();
+        mark(5);
         dump(b + 1);
     }
     dump(1000);
+    if (stamp) {
+        tprev = clock64();
+    }
 
     // ---- value head conv (py/module.py:89-94): conv1x1 C->256, LN, ReLU -> bf16 features in HBM
     {
@@ -520,9 +584,13 @@ __global__ __launch_bounds__(256, 1) void k_tower(TowerArgs A) {
         for (int mt = 0; mt < 4; mt++)
 #pragma unroll
             for (int i = 0; i < 4; i++) hv[mt][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        conv_mma<C, 1, 4, 16, true, CP, 4, 1>(0, net.wb + net.o_vconv, wave, lane, 0, hv);
         const float* f = net.wf + net.f_vhead;
-        bias_layernorm<4>(hv, f, f + HEAD, f + 2 * HEAD, HEAD, true, wave, lane, s_stat, s_mr, ln_parity);
+        LnP<4> P;
+        ln_load<4>(P, f, f + HEAD, f + 2 * HEAD, wave, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        bf16x8 hr[4][4];
+        conv_mma<C, 1, 4, 16, true, CP, 4, 1>(0, net.wb + net.o_vconv, wave, lane, 0, hv, hr, 0);
+        bias_layernorm<4>(hv, P, HEAD, true, wave, lane, s_stat, s_mr, ln_parity);
         const int c0 = chan0<4>(wave, lane);
 #pragma unroll
         for (int mt = 0; mt < 4; mt++)
@@ -542,9 +610,13 @@ __global__ __launch_bounds__(256, 1) void k_tower(TowerArgs A) {
         for (int mt = 0; mt < 4; mt++)
 #pragma unroll
             for (int i = 0; i < 4; i++) hp[mt][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        conv_mma<C, 1, 4, 16, true, CP, 4, 1>(0, net.wb + net.o_pconv1, wave, lane, 0, hp);
         const float* f = net.wf + net.f_phead1;
-        bias_layernorm<4>(hp, f, f + HEAD, f + 2 * HEAD, HEAD, false, wave, lane, s_stat, s_mr, ln_parity);
+        LnP<4> P;
+        ln_load<4>(P, f, f + HEAD, f + 2 * HEAD, wave, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        bf16x8 hr[4][4];
+        conv_mma<C, 1, 4, 16, true, CP, 4, 1>(0, net.wb + net.o_pconv1, wave, lane, 0, hp, hr, 0);
+        bias_layernorm<4>(hp, P, HEAD, false, wave, lane, s_stat, s_mr, ln_parity);
         store_image<4, false, HP>(hp, Xh, wave, lane);
     }
     __syncthreads();
@@ -554,10 +626,14 @@ __global__ __launch_bounds__(256, 1) void k_tower(TowerArgs A) {
         for (int mt = 0; mt < 4; mt++)
 #pragma unroll
             for (int i = 0; i < 2; i++) z[mt][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        conv_mma<HEAD, 1, 2, 8, false, HP, 4, 1>(XA_BYTES, net.wb + net.o_pconv2, wave, lane, 0, z);
         const float* f = net.wf + net.f_phead2;
+        LnP<2> P;
+        ln_load<2>(P, f, f + POL_PAD, f + 2 * POL_PAD, wave, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        bf16x8 hr[4][2];
+        conv_mma<HEAD, 1, 2, 8, false, HP, 4, 1>(XA_BYTES, net.wb + net.o_pconv2, wave, lane, 0, z, hr, 0);
         // padded channels (>=73) have zero weights, bias, gamma, beta: they add 0 to both LN sums
-        bias_layernorm<2>(z, f, f + POL_PAD, f + 2 * POL_PAD, 73, false, wave, lane, s_stat, s_mr, ln_parity);
+        bias_layernorm<2>(z, P, 73, false, wave, lane, s_stat, s_mr, ln_parity);
         __syncthreads();  // everyone is done with Xa/Xh: the logits may overwrite the image area
         const int c0 = chan0<2>(wave, lane);
 #pragma unroll
@@ -601,6 +677,10 @@ __global__ __launch_bounds__(256, 1) void k_tower(TowerArgs A) {
         __syncthreads();
         s = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]) + 1e-5f;  // post_process_distr (chess.rs:891)
         if (tid < n) A.prior[(size_t)pos * 224 + tid] = e / s;
+    }
+    if (stamp) {
+        mark(6);
+        for (int k = 0; k < 8; k++) A.dbg[(size_t)pos * 64 * C + k] = (float)tacc[k];
     }
 }
 
