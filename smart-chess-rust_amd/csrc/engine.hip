@@ -144,7 +144,8 @@ int sc_engine_create(const sc_net_config* cfg, const char* weights_path, int dev
         if (cfg->n_res_blocks < 0 || cfg->n_res_blocks > 80) return fail("n_res_blocks out of range");
         hw = scw::init_prng(cfg->n_res_blocks, cfg->channels, cfg->seed);
     }
-    scw::Packed pk = scw::pack(hw);
+    static const bool v32 = !(getenv("SC_TOWER_V") && atoi(getenv("SC_TOWER_V")) == 1);  // developer switch: 1 = 16x16x32 tower
+    scw::Packed pk = scw::pack(hw, v32);
     sc_engine* e = new sc_engine();
     e->device = device_id;
     const char* ierr = scl::nn_init();

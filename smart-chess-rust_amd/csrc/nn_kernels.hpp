@@ -63,8 +63,14 @@ __device__ __forceinline__ bf16x8 lds_frag(int byte_off) { return *reinterpret_c
 
 // 16-byte weight fragment through a wave-uniform buffer descriptor: voffset = lane*16 (loop invariant),
 // soffset = scalar cursor, imm = column-tile offset -> zero vector ALU per load.
+#ifdef SC_EXP
+__constant__ int g_exp_wand = -1;  // experiment builds only: confine the weight stream to a small window (L1/L2-hot)
+#endif
 __device__ __forceinline__ bf16x8 wload(__amdgpu_buffer_rsrc_t rsrc, int voff, int soff) {
     typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+#ifdef SC_EXP
+    soff &= g_exp_wand;
+#endif
     u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0);
     return __builtin_bit_cast(bf16x8, v);
 }
@@ -77,7 +83,9 @@ __device__ __forceinline__ bf16x8 wload(__amdgpu_buffer_rsrc_t rsrc, int voff, i
 // Ring carry: `bq` belongs to the caller.  With PRE the first RS-1 slots already hold this layer's first k-steps
 // (the previous layer's loop fetched them: its prefetches past its own last group go to byte offset `next_first`
 // relative to ITS weights, i.e. to the next layer), so a layer starts without an exposed L2 round trip.
-template <int CIN, int TAPS, int NTW, int NT_TOTAL, bool HALO, int CP, int RS, int TPI, bool PRE = false>
+// AB: A-fragment buffers; the LDS reads run AB-1 k-steps ahead (a k-step of the narrow trunk is only 128 MFMA cycles,
+// less than the LDS latency with four waves reading: one step ahead leaves the matrix pipe waiting on every m-tile).
+template <int CIN, int TAPS, int NTW, int NT_TOTAL, bool HALO, int CP, int RS, int TPI, bool PRE = false, int AB = 4>
 __device__ __forceinline__ void conv_mma(int xoff, const bf16_t* __restrict__ Wp, int wave_u, int lane, int t0,
                                          f32x4 (&acc)[4][NTW], bf16x8 (&bq)[RS][NTW], int next_first) {
     constexpr int KPT = CIN / 32;          // k-steps per tap
@@ -85,7 +93,9 @@ __device__ __forceinline__ void conv_mma(int xoff, const bf16_t* __restrict__ Wp
     constexpr int NG = TAPS / TPI;         // tap groups
     constexpr int SBB = NT_TOTAL * 1024;   // bytes per k-step of packed weights
     constexpr int PD = RS - 1;             // prefetch distance
+    constexpr int AD = AB - 1;             // A prefetch distance
     static_assert(TAPS % TPI == 0 && SPG % RS == 0 && PD < SPG, "bad ring / tap-group geometry");
+    static_assert(SPG % AB == 0 && AD <= SPG, "bad A buffer geometry");
     const int row16 = lane & 15, kq = lane >> 4;
     // LDS byte offsets of this lane's 4 A rows at the centre tap; tap offsets are scalars, k offsets immediates
     int pa[4];
@@ -101,7 +111,7 @@ __device__ __forceinline__ void conv_mma(int xoff, const bf16_t* __restrict__ Wp
     // B: ring of RS register slots, loads run RS-1 k-steps ahead of the MFMAs that consume them (the slot being
     // refilled was consumed one step earlier).  A: double-buffered LDS fragments, one step ahead.  Prefetches
     // past the last group wrap to the first one (valid memory, values unused).
-    bf16x8 aq[2][4];
+    bf16x8 aq[AB][4];
     int tg = t0;
     int wcur = tg * (SPG * SBB);
     int pc[TPI][4];
@@ -116,7 +126,9 @@ __device__ __forceinline__ void conv_mma(int xoff, const bf16_t* __restrict__ Wp
             for (int i = 0; i < NTW; i++) bq[st][i] = wload(rsrc, voff + i * 1024, wcur + st * SBB);
     }
 #pragma unroll
-    for (int mt = 0; mt < 4; mt++) aq[0][mt] = lds_frag(pc[0][mt]);
+    for (int v = 0; v < AD; v++)
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++) aq[v][mt] = lds_frag(pc[v / KPT][mt] + (v % KPT) * 64);
 #pragma unroll 1
     for (int j = 0; j < NG; j++) {
         int tn = tg + 1;
@@ -132,18 +144,27 @@ __device__ __forceinline__ void conv_mma(int xoff, const bf16_t* __restrict__ Wp
             constexpr int dummy = 0;
             (void)dummy;
             const int slot = u % RS;
+#ifndef SC_EXP_NOW
 #pragma unroll
             for (int i = 0; i < NTW; i++)
                 bq[(slot + PD) % RS][i] = (u + PD < SPG) ? wload(rsrc, voff + i * 1024, wcur + (u + PD) * SBB)
                                                          : wload(rsrc, voff + i * 1024, wnext + (u + PD - SPG) * SBB);
+#endif
+#ifndef SC_EXP_NOA
 #pragma unroll
-            for (int mt = 0; mt < 4; mt++)
-                aq[(u + 1) & 1][mt] = (u + 1 < SPG) ? lds_frag(pc[(u + 1) / KPT][mt] + ((u + 1) % KPT) * 64) : lds_frag(pn[0][mt]);
+            for (int mt = 0; mt < 4; mt++) {
+                constexpr int dummy2 = 0;
+                (void)dummy2;
+                const int v = u + AD;
+                aq[v % AB][mt] = (v < SPG) ? lds_frag(pc[v / KPT][mt] + (v % KPT) * 64)
+                                           : lds_frag(pn[(v - SPG) / KPT][mt] + ((v - SPG) % KPT) * 64);
+            }
+#endif
 #pragma unroll
             for (int mt = 0; mt < 4; mt++)
 #pragma unroll
                 for (int i = 0; i < NTW; i++)
-                    acc[mt][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[u & 1][mt], bq[slot][i], acc[mt][i], 0, 0, 0);
+                    acc[mt][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[u % AB][mt], bq[slot][i], acc[mt][i], 0, 0, 0);
             // Issue order inside the step: one m-tile of MFMAs, then one LDS read and one weight load, ... so the
             // matrix pipe never waits behind a burst of 8 memory instructions; the fence keeps every prefetch in
             // the step it was written in (otherwise the scheduler sinks loads to just before their use and the

@@ -1,0 +1,583 @@
+// nn_tower32.hpp -- the policy/value tower with CHANNELS on the MFMA row axis (v_mfma_f32_32x32x16_bf16).
+//
+// Same network, numerics contract and one-workgroup-per-position design as described in nn_kernels.hpp; what
+// changes is the GEMM orientation:   D[channel][pixel] += W^T[channel][k] * X[k][pixel]
+//   * A operand = weights, streamed L2 -> VGPR in 32x32x16 A-fragment order [k16 step][32-channel tile][lane][8]
+//     (natural channel order, 1 KiB per wave-load);  B operand = the LDS image, one ds_read_b128 per 32 pixels.
+//   * A k-step of the narrow trunk is 2 MFMAs of 32 cycles instead of 8 of 16: the same bytes and the same number
+//     of memory instructions ride under half as many, twice as long matrix instructions, so the wave has 24 free
+//     issue cycles per MFMA (8 with 16x16x32) to place its weight loads and LDS reads without stalling the pipe.
+//   * Accumulator layout: lane = pixel (lane&31 of a 32-pixel tile), registers = channels
+//     (8*(r>>2) + 4*(lane>>5) + (r&3)).  LayerNorm over channels is therefore an in-register sum plus ONE
+//     cross-lane add (lane ^ 32) and one LDS exchange between the 4 waves; a lane owns 4 ADJACENT channels per
+//     register quad, so activations go to LDS as 8-byte bf16 stores and the fp32 residual as 16-byte stores.
+//     Only the squeeze-excitation average pool reduces across lanes (halving butterfly, once per block).
+//   * Pixel tiles are chosen for the LDS banks: tile t holds ranks {2t, 2t+4} in ds_read_b128 lane group A and
+//     {2t+1, 2t+5} in group B; with a pixel stride of an odd multiple of 16 B the 16 haloed addresses of every
+//     lane group fall on 16 distinct 16-byte bank slots for every 3x3 tap.
+#pragma once
+#include "nn_kernels.hpp"
+
+namespace scnn {
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+// GEMM pixel (tile pt, lane-in-tile i) -> board pixel (rank*8 + file); see the header comment
+__device__ inline int gpix2board(int pt, int i) {
+    const bool inA = (i < 4) || (i >= 12 && i < 16) || (i >= 20 && i < 28);
+    const int a = inA ? (i < 4 ? i : (i < 16 ? i - 8 : i - 12)) : (i < 12 ? i - 4 : (i < 20 ? i - 8 : i - 16));
+    return ((2 * pt + (inA ? 0 : 1) + 4 * (a >> 3)) << 3) | (a & 7);
+}
+
+// first channel of register quad g (registers 4g..4g+3) of channel tile ct
+template <int CT>
+__device__ __forceinline__ int chan32(int wave, int ct, int g, int h) { return wave * (32 * CT) + ct * 32 + 8 * g + 4 * h; }
+
+// per-channel parameters in accumulator layout (a lane's 16*CT channels)
+template <int CT>
+struct ChP {
+    f32x4 v[CT][4];
+};
+template <int CT>
+__device__ __forceinline__ void ch_load(ChP<CT>& P, const float* __restrict__ p, int wave, int h) {
+#pragma unroll
+    for (int ct = 0; ct < CT; ct++)
+#pragma unroll
+        for (int g = 0; g < 4; g++) P.v[ct][g] = *reinterpret_cast<const f32x4*>(p + chan32<CT>(wave, ct, g, h));
+}
+// the conv bias is the accumulator's initial value
+template <int CT>
+__device__ __forceinline__ void acc_init(f32x16 (&acc)[CT][2], const ChP<CT>& B) {
+#pragma unroll
+    for (int ct = 0; ct < CT; ct++)
+#pragma unroll
+        for (int pt = 0; pt < 2; pt++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[ct][pt][r] = B.v[ct][r >> 2][r & 3];
+}
+
+// --------------------------------------------------------------------------------------------
+// Implicit GEMM, k-step 16.  acc[ct][pt] += W^T(32 channels x K) * X(K x 32 pixels).
+//   px[pt]: byte offset (inside the image at xoff) of this lane's pixel of tile pt, including its 16-byte k half
+//   weights: [K/16][TILES][64][8] bf16; this wave's tiles are wave*CT .. wave*CT+CT-1
+// Ring / carry semantics as conv_mma (nn_kernels.hpp): RS slots of one k-step each, loads run RS-1 steps ahead,
+// with PRE the first RS-1 slots were filled by the previous layer's loop (its last prefetches go to `next_first`,
+// a byte offset relative to ITS weights).  AB image-fragment buffers, reads AB-1 steps ahead.
+template <int CIN, int TAPS, int CT, int TILES, int CP, int RS, int TPI, bool PRE, int AB = 4>
+__device__ __forceinline__ void conv_mma32(int xoff, const bf16_t* __restrict__ Wp, int wave_u, int lane, const int (&px)[2],
+                                           f32x16 (&acc)[CT][2], bf16x8 (&bq)[RS][CT], int next_first) {
+    constexpr int KPT = CIN / 16;          // k-steps per tap
+    constexpr int SPG = KPT * TPI;         // k-steps per loop iteration (tap group)
+    constexpr int NG = TAPS / TPI;
+    constexpr int SBB = TILES * 1024;      // bytes per k-step of packed weights
+    constexpr int PD = RS - 1, AD = AB - 1;
+    static_assert(TAPS % TPI == 0 && SPG % RS == 0 && PD < SPG, "bad ring / tap-group geometry");
+    static_assert(SPG % AB == 0 && AD <= SPG, "bad image buffer geometry");
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<bf16_t*>(Wp) + (size_t)wave_u * CT * 512, 0, 0x7fffffff, 0x00020000);
+    const int voff = lane * 16;
+    auto toffb = [](int t) { return (TAPS == 9) ? ((((t * 11) >> 5) - 1) * 10 + (t - 3 * ((t * 11) >> 5)) - 1) * CP * 2 : 0; };
+    bf16x8 xq[AB][2];
+    int wcur = 0;
+    int pc[TPI][2];
+#pragma unroll
+    for (int tl = 0; tl < TPI; tl++)
+#pragma unroll
+        for (int pt = 0; pt < 2; pt++) pc[tl][pt] = xoff + px[pt] + toffb(tl);
+    if (!PRE) {
+#pragma unroll
+        for (int st = 0; st < PD; st++)
+#pragma unroll
+            for (int ct = 0; ct < CT; ct++) bq[st][ct] = wload(rsrc, voff + ct * 1024, st * SBB);
+    }
+#pragma unroll
+    for (int v = 0; v < AD; v++)
+#pragma unroll
+        for (int pt = 0; pt < 2; pt++) xq[v][pt] = lds_frag(pc[v / KPT][pt] + (v % KPT) * 32);
+#pragma unroll 1
+    for (int j = 0; j < NG; j++) {
+        const int tn = (j + 1 == NG) ? 0 : j + 1;
+        const int wnext = (j == NG - 1) ? next_first : tn * (SPG * SBB);
+        int pn[TPI][2];
+#pragma unroll
+        for (int tl = 0; tl < TPI; tl++)
+#pragma unroll
+            for (int pt = 0; pt < 2; pt++) pn[tl][pt] = xoff + px[pt] + toffb(tn * TPI + tl);
+#pragma unroll
+        for (int u = 0; u < SPG; u++) {
+            const int slot = u % RS;
+#pragma unroll
+            for (int ct = 0; ct < CT; ct++)
+                bq[(slot + PD) % RS][ct] = (u + PD < SPG) ? wload(rsrc, voff + ct * 1024, wcur + (u + PD) * SBB)
+                                                          : wload(rsrc, voff + ct * 1024, wnext + (u + PD - SPG) * SBB);
+#pragma unroll
+            for (int pt = 0; pt < 2; pt++) {
+                const int v = u + AD;
+                xq[v % AB][pt] = (v < SPG) ? lds_frag(pc[v / KPT][pt] + (v % KPT) * 32)
+                                           : lds_frag(pn[(v - SPG) / KPT][pt] + ((v - SPG) % KPT) * 32);
+            }
+#pragma unroll
+            for (int ct = 0; ct < CT; ct++)
+#pragma unroll
+                for (int pt = 0; pt < 2; pt++)
+                    acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq[slot][ct], xq[u % AB][pt], acc[ct][pt], 0, 0, 0);
+            // one memory instruction behind each MFMA; the fence keeps every prefetch in the step it was written in
+#pragma unroll
+            for (int m = 0; m < 2 * CT; m++) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if (CT == 1) {
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    if (m == 0) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                } else {
+                    if ((m & 1) == 0)
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    else
+                        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        wcur = wnext;
+#pragma unroll
+        for (int tl = 0; tl < TPI; tl++)
+#pragma unroll
+            for (int pt = 0; pt < 2; pt++) pc[tl][pt] = pn[tl][pt];
+    }
+}
+
+// LayerNorm over `count` channels (eps 1e-6, timm LayerNorm2d) + optional ReLU, in place; the bias is already in
+// the accumulators.  s_stat2: two alternating [4 waves][64 pixels] float2 buffers (one barrier per LayerNorm, as
+// in bias_layernorm).  Pixels are indexed by GEMM pixel (pt*32 + lane&31).
+template <int CT>
+__device__ inline void layernorm32(f32x16 (&acc)[CT][2], const ChP<CT>& G, const ChP<CT>& E, int count, bool relu, int wave,
+                                   int lane, float* s_stat2, int& parity) {
+    float2* st = reinterpret_cast<float2*>(s_stat2) + (parity & 1) * 256;
+    parity ^= 1;
+    const int i = lane & 31;
+    float s[2], q[2];
+#pragma unroll
+    for (int pt = 0; pt < 2; pt++) {
+        float a = 0.f, b = 0.f;
+#pragma unroll
+        for (int ct = 0; ct < CT; ct++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                float v = acc[ct][pt][r];
+                a += v;
+                b += v * v;
+            }
+        s[pt] = a + __shfl_xor(a, 32, 64);
+        q[pt] = b + __shfl_xor(b, 32, 64);
+    }
+    if (lane < 32) {
+        st[wave * 64 + i] = make_float2(s[0], q[0]);
+        st[wave * 64 + 32 + i] = make_float2(s[1], q[1]);
+    }
+    __syncthreads();
+    const float inv = 1.0f / (float)count;
+#pragma unroll
+    for (int pt = 0; pt < 2; pt++) {
+        const int gp = pt * 32 + i;
+        float2 a0 = st[gp], a1 = st[64 + gp], a2 = st[128 + gp], a3 = st[192 + gp];
+        float S = (a0.x + a1.x) + (a2.x + a3.x);
+        float Q = (a0.y + a1.y) + (a2.y + a3.y);
+        float mean = S * inv;
+        float var = Q * inv - mean * mean;
+        var = var < 0.f ? 0.f : var;
+        float rstd = 1.0f / sqrtf(var + 1e-6f);
+        float nm = -mean * rstd;
+#pragma unroll
+        for (int ct = 0; ct < CT; ct++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                float t = acc[ct][pt][r] * rstd + nm;
+                float y = t * G.v[ct][r >> 2][r & 3] + E.v[ct][r >> 2][r & 3];
+                acc[ct][pt][r] = (relu && y < 0.f) ? 0.f : y;
+            }
+    }
+}
+
+// accumulators -> bf16 image: pixbase[pt] = byte offset of the lane's pixel row inside g_smem, 4 adjacent channels
+// per 8-byte store
+template <int CT>
+__device__ inline void store_image32(const f32x16 (&acc)[CT][2], const int (&pixbase)[2], int wave, int h) {
+#pragma unroll
+    for (int ct = 0; ct < CT; ct++)
+#pragma unroll
+        for (int pt = 0; pt < 2; pt++)
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                uint2 v;
+                v.x = (uint32_t)f2bf(acc[ct][pt][4 * g]) | ((uint32_t)f2bf(acc[ct][pt][4 * g + 1]) << 16);
+                v.y = (uint32_t)f2bf(acc[ct][pt][4 * g + 2]) | ((uint32_t)f2bf(acc[ct][pt][4 * g + 3]) << 16);
+                *reinterpret_cast<uint2*>(g_smem + pixbase[pt] + chan32<CT>(wave, ct, g, h) * 2) = v;
+            }
+}
+
+// one level of the halving butterfly over the 32 lanes of a half-wave: lanes with BIT set keep the upper W values
+// (W = 0: a single value is left, plain exchange-add)
+template <int NV, int W, int BIT>
+__device__ __forceinline__ void pool_level(float (&v)[NV], int lane) {
+    if constexpr (W >= 1) {
+        const bool hi = (lane & BIT) != 0;
+#pragma unroll
+        for (int t = 0; t < W; t++) {
+            float send = hi ? v[t] : v[t + W], keep = hi ? v[t + W] : v[t];
+            v[t] = keep + __shfl_xor(send, BIT, 64);
+        }
+        pool_level<NV, W / 2, BIT / 2>(v, lane);
+    } else if constexpr (BIT >= 1) {
+        v[0] += __shfl_xor(v[0], BIT, 64);
+        pool_level<NV, 0, BIT / 2>(v, lane);
+    }
+}
+
+constexpr int tower32_lds_bytes(int C) {
+    const int xa = 100 * (C + 8) * 2;
+    const int r1 = 64 * (C + 4) * 4, r2 = 64 * (HEAD + 8) * 2;
+    return xa + (r1 > r2 ? r1 : r2) + 4096 + 3072 + 1024 + 64;
+}
+
+template <int C, int RS, int TPI>
+__global__ __launch_bounds__(256, 1) void k_tower32(TowerArgs A) {
+    constexpr int CT = C / 128;        // 32-channel tiles per wave in the trunk
+    constexpr int TILES = C / 32;
+    constexpr int CP = C + 8;          // image pixel stride (elements): (C+8)*2 B is an odd multiple of 16 B
+    constexpr int HP = HEAD + 8;
+    constexpr int RP = C + 4;          // residual row stride (floats): odd multiple of 16 B
+    constexpr int NTW = C / 64;        // 16-column tiles per wave of the SE layers (16x16x32 vector products)
+    constexpr int XA_BYTES = 100 * CP * 2;
+    constexpr int RS_BYTES = (64 * RP * 4 > 64 * HP * 2) ? 64 * RP * 4 : 64 * HP * 2;
+    unsigned char* smem = g_smem;
+    bf16_t* Xa = reinterpret_cast<bf16_t*>(smem);                           // [100][CP] bf16 haloed image
+    float* Rs = reinterpret_cast<float*>(smem + XA_BYTES);                  // [64][RP] fp32 residual stream (GEMM pixel order)
+    float* s_stat = reinterpret_cast<float*>(smem + XA_BYTES + RS_BYTES);   // 2 x [4][64] float2
+    float* s_vec = s_stat + 1024;                                           // SE vectors (packed bf16)
+    float* s_scl = s_vec + 768;                                             // [C] SE scales
+    float* s_red = s_scl + 256;                                             // [8]
+    bf16_t* s_xb = reinterpret_cast<bf16_t*>(s_vec);
+    float* s_z = reinterpret_cast<float*>(smem);                            // policy logits [4672], aliases Xa (after the trunk)
+    static_assert(4672 * 4 <= XA_BYTES, "policy logits must fit in the image area");
+    static_assert(XA_BYTES % 16 == 0 && RS_BYTES % 16 == 0, "LDS regions must stay 16-byte aligned");
+
+    const int pos = blockIdx.x;
+    if (pos >= A.n_pos) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i32 = lane & 31, h = lane >> 5;
+    const NetDev& net = A.net;
+    const int bp[2] = {gpix2board(0, i32), gpix2board(1, i32)};            // this lane's two board pixels
+    const int pixbase[2] = {hidx(bp[0]) * CP * 2, hidx(bp[1]) * CP * 2};   // their rows in the haloed image (bytes)
+    const int px[2] = {pixbase[0] + h * 16, pixbase[1] + h * 16};          // + this lane's k half
+
+    // ---- zero the image (halo stays zero for the whole kernel), then load the 112 input planes
+    {
+        uint4* z = reinterpret_cast<uint4*>(Xa);
+        for (int k = tid; k < 100 * CP * 2 / 16; k += 256) z[k] = make_uint4(0, 0, 0, 0);
+    }
+    __syncthreads();
+    {
+        const int p = tid >> 2, q = tid & 3;
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(A.boards + (size_t)pos * 7168 + p * 112 + q * 28);
+        bf16_t* dst = Xa + hidx(p) * CP + q * 28;
+#pragma unroll
+        for (int k = 0; k < 7; k++) {
+            uint32_t w = src[k];
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                int8_t v = (int8_t)((w >> (8 * b)) & 0xff);
+                dst[k * 4 + b] = f2bf((float)v);
+            }
+        }
+    }
+    __syncthreads();
+
+    f32x16 acc[CT][2];
+    int ln_parity = 0;
+    auto store_res = [&]() {
+#pragma unroll
+        for (int ct = 0; ct < CT; ct++)
+#pragma unroll
+            for (int pt = 0; pt < 2; pt++)
+#pragma unroll
+                for (int g = 0; g < 4; g++)
+                    *reinterpret_cast<f32x4*>(Rs + (pt * 32 + i32) * RP + chan32<CT>(wave, ct, g, h)) =
+                        f32x4{acc[ct][pt][4 * g], acc[ct][pt][4 * g + 1], acc[ct][pt][4 * g + 2], acc[ct][pt][4 * g + 3]};
+    };
+    auto dump = [&](int stage) {
+        if (A.dbg && A.dbg_stage == stage) {
+#pragma unroll
+            for (int ct = 0; ct < CT; ct++)
+#pragma unroll
+                for (int pt = 0; pt < 2; pt++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++)
+                        A.dbg[((size_t)pos * 64 + bp[pt]) * C + chan32<CT>(wave, ct, r >> 2, h) + (r & 3)] = acc[ct][pt][r];
+        }
+    };
+
+    bf16x8 ring[RS][CT];   // weight prefetch ring, carried from layer to layer
+    ChP<CT> Bn;            // bias of the NEXT conv (requested one epilogue early)
+    // ---- conv_block (py/module.py:120-126): conv3x3 112->C (K padded to 128/tap), LN, ReLU
+    {
+        const float* f = net.wf + net.f_stem;
+        ch_load<CT>(Bn, f, wave, h);
+        acc_init<CT>(acc, Bn);
+        const bf16_t* w0 = net.wb + net.o_stem;
+        conv_mma32<128, 9, CT, TILES, CP, RS, TPI, false>(0, w0, wave, lane, px, acc, ring, (int)((net.wb + net.o_blocks) - w0) * 2);
+        ChP<CT> G, E;
+        ch_load<CT>(G, f + C, wave, h);
+        ch_load<CT>(E, f + 2 * C, wave, h);
+        ch_load<CT>(Bn, net.wf + net.f_blocks, wave, h);
+        __builtin_amdgcn_sched_barrier(0);
+        layernorm32<CT>(acc, G, E, C, true, wave, lane, s_stat, ln_parity);
+    }
+    store_res();
+    store_image32<CT>(acc, pixbase, wave, h);  // every wave passed the LN barrier: the input image is dead
+    __syncthreads();
+    dump(0);
+
+    // developer aid: dbg_stage 2000 -> cycle stamps (summed over blocks) of the block's phases in dbg[pos][0..7]
+    const bool stamp = A.dbg && A.dbg_stage == 2000 && tid == 0;
+    long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long tprev = 0;
+    auto mark = [&](int k) {
+        if (stamp) {
+            long long t = clock64();
+            tacc[k] += t - tprev;
+            tprev = t;
+        }
+    };
+    // ---- residual tower (ResBlockSE.forward, py/module.py:38-46)
+#pragma unroll 1
+    for (int b = 0; b < net.n_blocks; b++) {
+        const bf16_t* wb = net.wb + net.o_blocks + (size_t)b * net.blk_stride_b;
+        const float* wf = net.wf + net.f_blocks + (size_t)b * net.blk_stride_f;
+        constexpr int NT1 = C / 32;                       // 16-column tiles of SE fc1
+        constexpr bool FULL1 = (C == 128);
+        constexpr int NTW1 = FULL1 ? NT1 : NT1 / 4;
+        constexpr int PW1 = NT1 / 4;                      // fc1 tiles per wave in the packed column order
+        if (stamp) tprev = clock64();
+        // conv1 -> LN -> ReLU.  Per-channel parameters are requested right after the loop that precedes their use.
+        acc_init<CT>(acc, Bn);
+        conv_mma32<C, 9, CT, TILES, CP, RS, TPI, true>(0, wb, wave, lane, px, acc, ring, 9 * C * C * 2);
+        mark(0);
+        {
+            ChP<CT> G, E;
+            ch_load<CT>(G, wf + C, wave, h);
+            ch_load<CT>(E, wf + 2 * C, wave, h);
+            ch_load<CT>(Bn, wf + 3 * C, wave, h);
+            __builtin_amdgcn_sched_barrier(0);
+            layernorm32<CT>(acc, G, E, C, true, wave, lane, s_stat, ln_parity);
+        }
+        store_image32<CT>(acc, pixbase, wave, h);
+        __syncthreads();
+        mark(1);
+        // conv2 -> LN
+        acc_init<CT>(acc, Bn);
+        {
+            // the loop's last prefetches fetch the first k-steps of the NEXT block's conv1 (or wrap on the last block)
+            const int nxt = (b + 1 < net.n_blocks) ? (int)(net.blk_stride_b - (size_t)9 * C * C) * 2 : 0;
+            conv_mma32<C, 9, CT, TILES, CP, RS, TPI, true>(0, wb + (size_t)9 * C * C, wave, lane, px, acc, ring, nxt);
+        }
+        mark(2);
+        // squeeze-excitation weights and all remaining parameters of the block are requested now: their L2 round
+        // trip hides under the LayerNorm.  Narrow trunk: every wave computes the whole C -> C/2 layer itself.
+        VecW<C, NTW1> w1;
+        VecW<C / 2, NTW> w2;
+        float b1v[NTW1], b2v[NTW];
+        {
+            ChP<CT> G, E;
+            ch_load<CT>(G, wf + 4 * C, wave, h);
+            ch_load<CT>(E, wf + 5 * C, wave, h);
+            ch_load<CT>(Bn, (b + 1 < net.n_blocks) ? wf + net.blk_stride_f : wf, wave, h);
+            vec_w_load<C, NTW1, NT1>(w1, wb + (size_t)18 * C * C, FULL1 ? 0 : wave * NTW1, lane);
+            vec_w_load<C / 2, NTW, C / 16>(w2, wb + (size_t)18 * C * C + (size_t)C * (C / 2), wave * NTW, lane);
+            const float* b1 = wf + 6 * C;
+            const float* b2 = wf + 6 * C + C / 2;
+            const int c0 = chan0<NTW>(wave, lane);
+#pragma unroll
+            for (int k = 0; k < NTW1; k++) {
+                // packed column (tile, lane) -> hidden channel: tiles were laid out for a 4-wave split
+                const int tile = FULL1 ? k : wave * NTW1 + k;
+                b1v[k] = b1[(tile / PW1) * (16 * PW1) + (lane & 15) * PW1 + (tile % PW1)];
+            }
+#pragma unroll
+            for (int k = 0; k < NTW; k++) b2v[k] = b2[c0 + k];
+            __builtin_amdgcn_sched_barrier(0);
+            layernorm32<CT>(acc, G, E, C, false, wave, lane, s_stat, ln_parity);
+        }
+        mark(3);
+        // global average pool over the 64 pixels: in-lane over the two tiles, then a halving butterfly over the
+        // 32 lanes of a half-wave (lane j of a half ends up with register index j, or j>>1 when there are 16)
+        {
+            constexpr int NV = 16 * CT;
+            float v[NV];
+#pragma unroll
+            for (int ct = 0; ct < CT; ct++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) v[ct * 16 + r] = acc[ct][0][r] + acc[ct][1][r];
+            pool_level<NV, NV / 2, 16>(v, lane);
+            const int idx = (NV == 32) ? i32 : (i32 >> 1);
+            s_xb[chan32<CT>(wave, idx >> 4, (idx & 15) >> 2, h) + (idx & 3)] = f2bf(v[0] * (1.0f / 64.0f));  // conv inputs are bf16 (autocast)
+        }
+        __syncthreads();
+        bf16_t* s_hid = s_xb + 256 + (FULL1 ? wave * 128 : 0);   // hidden vector (wave-private when FULL1)
+        {
+            // fc1: C -> C/2, ReLU
+            f32x4 hh[NTW1];
+#pragma unroll
+            for (int k = 0; k < NTW1; k++) hh[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+            vec_mma<C, NTW1>(s_xb, w1, lane, hh);
+            if (lane < 16) {
+#pragma unroll
+                for (int k = 0; k < NTW1; k++) {
+                    const int tile = FULL1 ? k : wave * NTW1 + k;
+                    const int j = (tile / PW1) * (16 * PW1) + (lane & 15) * PW1 + (tile % PW1);
+                    float t = hh[k][0] + b1v[k];
+                    s_hid[j] = f2bf(t > 0.f ? t : 0.f);
+                }
+            }
+        }
+        if (!FULL1) __syncthreads();  // FULL1: the hidden vector is wave-private (DS ops of a wave execute in order)
+        {
+            // fc2: C/2 -> C, sigmoid; every wave produces the scales of exactly its own channels and hands them to
+            // its lanes through LDS (wave-private, no barrier)
+            f32x4 sc[NTW];
+#pragma unroll
+            for (int k = 0; k < NTW; k++) sc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+            vec_mma<C / 2, NTW>(s_hid, w2, lane, sc);
+            if (lane < 16) {
+                const int c0 = chan0<NTW>(wave, lane);
+#pragma unroll
+                for (int k = 0; k < NTW; k++) s_scl[c0 + k] = 1.0f / (1.0f + __expf(-(sc[k][0] + b2v[k])));
+            }
+        }
+        mark(4);
+#pragma unroll
+        for (int ct = 0; ct < CT; ct++)
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const int ch = chan32<CT>(wave, ct, g, h);
+                const f32x4 sv = *reinterpret_cast<const f32x4*>(s_scl + ch);
+#pragma unroll
+                for (int pt = 0; pt < 2; pt++) {
+                    const f32x4 rv = *reinterpret_cast<const f32x4*>(Rs + (pt * 32 + i32) * RP + ch);
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        float y = acc[ct][pt][4 * g + k] * sv[k] + rv[k];
+                        acc[ct][pt][4 * g + k] = y > 0.f ? y : 0.f;
+                    }
+                }
+            }
+        store_res();                               // each lane rewrites exactly the cells it just read
+        store_image32<CT>(acc, pixbase, wave, h);  // conv2 finished reading Xa before the SE barriers
+        __syncthreads();
+        mark(5);
+        dump(b + 1);
+    }
+    dump(1000);
+    if (stamp) tprev = clock64();
+
+    const int gpb[2] = {(i32 * HP) * 2, ((32 + i32) * HP) * 2};   // rows of the plain (non-haloed) policy image
+    // ---- value head conv (py/module.py:89-94): conv1x1 C->256, LN, ReLU -> bf16 features in HBM
+    {
+        const float* f = net.wf + net.f_vhead;
+        ChP<2> Bv, G, E;
+        ch_load<2>(Bv, f, wave, h);
+        ch_load<2>(G, f + HEAD, wave, h);
+        ch_load<2>(E, f + 2 * HEAD, wave, h);
+        f32x16 hv[2][2];
+        acc_init<2>(hv, Bv);
+        bf16x8 hr[4][2];
+        conv_mma32<C, 1, 2, 8, CP, 4, 1, false>(0, net.wb + net.o_vconv, wave, lane, px, hv, hr, 0);
+        layernorm32<2>(hv, G, E, HEAD, true, wave, lane, s_stat, ln_parity);
+#pragma unroll
+        for (int ct = 0; ct < 2; ct++)
+#pragma unroll
+            for (int pt = 0; pt < 2; pt++)
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    uint2 v;
+                    v.x = (uint32_t)f2bf(hv[ct][pt][4 * g]) | ((uint32_t)f2bf(hv[ct][pt][4 * g + 1]) << 16);
+                    v.y = (uint32_t)f2bf(hv[ct][pt][4 * g + 2]) | ((uint32_t)f2bf(hv[ct][pt][4 * g + 3]) << 16);
+                    *reinterpret_cast<uint2*>(A.hval + ((size_t)pos * 64 + bp[pt]) * HEAD + chan32<2>(wave, ct, g, h)) = v;
+                }
+    }
+    // ---- policy head (py/module.py:70-76): conv1x1 C->256, LN, conv1x1 256->73, LN (no ReLU between)
+    {
+        const float* f = net.wf + net.f_phead1;
+        ChP<2> Bv, G, E;
+        ch_load<2>(Bv, f, wave, h);
+        ch_load<2>(G, f + HEAD, wave, h);
+        ch_load<2>(E, f + 2 * HEAD, wave, h);
+        f32x16 hp[2][2];
+        acc_init<2>(hp, Bv);
+        bf16x8 hr[4][2];
+        conv_mma32<C, 1, 2, 8, CP, 4, 1, false>(0, net.wb + net.o_pconv1, wave, lane, px, hp, hr, 0);
+        layernorm32<2>(hp, G, E, HEAD, false, wave, lane, s_stat, ln_parity);
+        const int xb[2] = {XA_BYTES + gpb[0], XA_BYTES + gpb[1]};
+        store_image32<2>(hp, xb, wave, h);   // Xh aliases the residual area (dead after the trunk)
+    }
+    __syncthreads();
+    {
+        const float* f = net.wf + net.f_phead2;
+        ChP<1> Bv, G, E;
+        ch_load<1>(Bv, f, wave, h);
+        ch_load<1>(G, f + POL_PAD, wave, h);
+        ch_load<1>(E, f + 2 * POL_PAD, wave, h);
+        f32x16 z[1][2];
+        acc_init<1>(z, Bv);
+        bf16x8 hr[4][1];
+        const int pxh[2] = {gpb[0] + h * 16, gpb[1] + h * 16};
+        conv_mma32<HEAD, 1, 1, 4, HP, 4, 1, false>(XA_BYTES, net.wb + net.o_pconv2, wave, lane, pxh, z, hr, 0);
+        // padded channels (>=73) have zero weights, bias, gamma, beta: they add 0 to both LN sums
+        layernorm32<1>(z, G, E, 73, false, wave, lane, s_stat, ln_parity);
+        __syncthreads();  // everyone is done with Xa/Xh: the logits may overwrite the image area
+#pragma unroll
+        for (int pt = 0; pt < 2; pt++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int ch = chan32<1>(wave, 0, r >> 2, h) + (r & 3);
+                if (ch < 73) s_z[ch * 64 + bp[pt]] = z[0][pt][r];  // Flatten is channel-major (module.py:75)
+            }
+    }
+    __syncthreads();
+    // ---- log_softmax over 4672 (module.py:80), then the legal-move gather of torch.rs:148-175
+    float mx = -3.0e38f;
+    for (int k = tid; k < 4672; k += 256) mx = fmaxf(mx, s_z[k]);
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    if (lane == 0) s_red[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+    float se = 0.f;
+    for (int k = tid; k < 4672; k += 256) se += __expf(s_z[k] - mx);
+    for (int o = 32; o > 0; o >>= 1) se += __shfl_xor(se, o, 64);
+    if (lane == 0) s_red[4 + wave] = se;
+    __syncthreads();
+    se = (s_red[4] + s_red[5]) + (s_red[6] + s_red[7]);
+    const float lse = mx + __logf(se);
+    if (A.logp) {
+        float* lp = A.logp + (size_t)pos * 4672;
+        for (int k = tid; k < 4672; k += 256) lp[k] = s_z[k] - lse;
+    }
+    if (A.prior) {
+        const int n = A.n_legal[pos];
+        const uint16_t* li = A.legal_idx + (size_t)pos * 224;
+        float e = 0.f;
+        if (tid < n) e = __expf(s_z[li[tid]] - lse);  // n <= 218 < 256 threads
+        float s = e;
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        __syncthreads();
+        if (lane == 0) s_red[wave] = s;
+        __syncthreads();
+        s = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]) + 1e-5f;  // post_process_distr (chess.rs:891)
+        if (tid < n) A.prior[(size_t)pos * 224 + tid] = e / s;
+    }
+    if (stamp) {
+        mark(6);
+        for (int k = 0; k < 8; k++) A.dbg[(size_t)pos * 64 * C + k] = (float)tacc[k];
+    }
+}
+
+}  // namespace scnn

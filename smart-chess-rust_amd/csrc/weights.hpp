@@ -147,18 +147,34 @@ inline void pack_B(uint16_t* out, int K, int NT_TOTAL, int NTW, F getB) {
                 }
 }
 
+// W[k][n] accessor -> packed [K/16][TILES][64][8]: v_mfma_f32_32x32x16_bf16 A-fragment order for the transposed
+// (channels on rows) tower, natural channel order (nn_tower32.hpp)
+template <class F>
+inline void pack_A32(uint16_t* out, int K, int TILES, F getW) {
+    const int S = K / 16;
+    for (int s = 0; s < S; s++)
+        for (int t = 0; t < TILES; t++)
+            for (int l = 0; l < 64; l++)
+                for (int j = 0; j < 8; j++) {
+                    int n = t * 32 + (l & 31);
+                    int k = s * 16 + 8 * (l >> 5) + j;
+                    out[(((size_t)s * TILES + t) * 64 + l) * 8 + j] = f2bf(getW(k, n));
+                }
+}
+
 struct Packed {
     std::vector<uint16_t> wb;
     std::vector<float> wf;
     scnn::NetLayout lay;
 };
 
-inline Packed pack(const HostWeights& w) {
+inline Packed pack(const HostWeights& w, bool v32 = true) {
     const int C = w.C, nb = w.n_blocks, H = 256;
     Packed p;
     scnn::NetLayout& L = p.lay;
     L.n_blocks = nb;
     L.C = C;
+    L.tower32 = v32 ? 1 : 0;
     size_t ob = 0, of = 0;
     L.o_stem = ob; ob += (size_t)9 * 128 * C;
     L.o_blocks = ob; L.blk_stride_b = (size_t)18 * C * C + (size_t)C * (C / 2) * 2; ob += L.blk_stride_b * nb;
@@ -182,10 +198,12 @@ inline Packed pack(const HostWeights& w) {
     // stem: conv_block.0 [C][112][3][3], K padded to 128 per tap
     {
         const float* W = w.t[0].data();
-        pack_B(p.wb.data() + L.o_stem, 9 * 128, NT, NTW, [&](int k, int n) {
+        auto get = [&](int k, int n) {
             int tap = k / 128, ci = k % 128;
             return ci < 112 ? W[((size_t)n * 112 + ci) * 9 + tap] : 0.f;
-        });
+        };
+        if (v32) pack_A32(p.wb.data() + L.o_stem, 9 * 128, C / 32, get);
+        else pack_B(p.wb.data() + L.o_stem, 9 * 128, NT, NTW, get);
         for (int c = 0; c < C; c++) {
             p.wf[L.f_stem + c] = w.t[1][c];
             p.wf[L.f_stem + C + c] = w.t[2][c];
@@ -198,10 +216,12 @@ inline Packed pack(const HostWeights& w) {
         float* wf = p.wf.data() + L.f_blocks + (size_t)b * L.blk_stride_f;
         for (int cv = 0; cv < 2; cv++) {
             const float* W = w.t[t0 + 4 * cv].data();
-            pack_B(wb + (size_t)cv * 9 * C * C, 9 * C, NT, NTW, [&](int k, int n) {
+            auto get = [&](int k, int n) {
                 int tap = k / C, ci = k % C;
                 return W[((size_t)n * C + ci) * 9 + tap];
-            });
+            };
+            if (v32) pack_A32(wb + (size_t)cv * 9 * C * C, 9 * C, C / 32, get);
+            else pack_B(wb + (size_t)cv * 9 * C * C, 9 * C, NT, NTW, get);
             for (int c = 0; c < C; c++) {
                 wf[(3 * cv + 0) * C + c] = w.t[t0 + 4 * cv + 1][c];
                 wf[(3 * cv + 1) * C + c] = w.t[t0 + 4 * cv + 2][c];
@@ -221,7 +241,9 @@ inline Packed pack(const HostWeights& w) {
     int vt = 4 + 12 * nb, pt = vt + 8;
     {
         const float* W = w.t[vt].data();  // [256][C]
-        pack_B(p.wb.data() + L.o_vconv, C, 16, 4, [&](int k, int n) { return W[(size_t)n * C + k]; });
+        auto getv = [&](int k, int n) { return W[(size_t)n * C + k]; };
+        if (v32) pack_A32(p.wb.data() + L.o_vconv, C, 8, getv);
+        else pack_B(p.wb.data() + L.o_vconv, C, 16, 4, getv);
         for (int c = 0; c < H; c++) {
             p.wf[L.f_vhead + c] = w.t[vt + 1][c];
             p.wf[L.f_vhead + H + c] = w.t[vt + 2][c];
@@ -241,14 +263,18 @@ inline Packed pack(const HostWeights& w) {
     }
     {
         const float* W = w.t[pt].data();
-        pack_B(p.wb.data() + L.o_pconv1, C, 16, 4, [&](int k, int n) { return W[(size_t)n * C + k]; });
+        auto getp = [&](int k, int n) { return W[(size_t)n * C + k]; };
+        if (v32) pack_A32(p.wb.data() + L.o_pconv1, C, 8, getp);
+        else pack_B(p.wb.data() + L.o_pconv1, C, 16, 4, getp);
         for (int c = 0; c < H; c++) {
             p.wf[L.f_phead1 + c] = w.t[pt + 1][c];
             p.wf[L.f_phead1 + H + c] = w.t[pt + 2][c];
             p.wf[L.f_phead1 + 2 * H + c] = w.t[pt + 3][c];
         }
         const float* W2 = w.t[pt + 4].data();  // [73][256]
-        pack_B(p.wb.data() + L.o_pconv2, H, 8, 2, [&](int k, int n) { return n < 73 ? W2[(size_t)n * H + k] : 0.f; });
+        auto getp2 = [&](int k, int n) { return n < 73 ? W2[(size_t)n * H + k] : 0.f; };
+        if (v32) pack_A32(p.wb.data() + L.o_pconv2, H, 4, getp2);
+        else pack_B(p.wb.data() + L.o_pconv2, H, 8, 2, getp2);
         for (int c = 0; c < 73; c++) {
             p.wf[L.f_phead2 + c] = w.t[pt + 5][c];
             p.wf[L.f_phead2 + 128 + c] = w.t[pt + 6][c];

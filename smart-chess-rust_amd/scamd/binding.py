@@ -5,7 +5,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libsc_engine.so")
+# SC_ENGINE_LIB: developer override (experiment builds of the same library); there is still no CPU fallback
+_LIB_PATH = os.environ.get("SC_ENGINE_LIB") or os.path.join(os.path.dirname(_HERE), "lib", "libsc_engine.so")
 
 MAX_MOVES = 224
 TERMINATION = {0: None, 1: "Checkmate", 2: "Stalemate", 3: "InsufficientMaterial", 4: "SeventyfiveMoves",
