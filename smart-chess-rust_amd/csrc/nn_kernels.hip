@@ -48,7 +48,7 @@ const char* nn_init() {
 }
 void tower(const scnn::TowerArgs& a, hipStream_t s) {
     if (a.n_pos <= 0) return;
-    static const int ring = getenv("SC_TOWER_RING") ? atoi(getenv("SC_TOWER_RING")) : 4;     // experiment knobs
+    static const int ring = getenv("SC_TOWER_RING") ? atoi(getenv("SC_TOWER_RING")) : 12;     // experiment knobs
     static const int stagger = getenv("SC_TOWER_STAGGER") ? atoi(getenv("SC_TOWER_STAGGER")) : 0;
     scnn::TowerArgs b = a;
     b.stagger = stagger;

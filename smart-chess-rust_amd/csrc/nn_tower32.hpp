@@ -22,6 +22,30 @@ namespace scnn {
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
+// experiment builds (-DSC_EXP, tools/build_exp.sh): per-wave cycle stamps of the block phases, dumped with dbg_stage 2000
+#ifdef SC_EXP
+struct Stamp {
+    bool on;
+    long long prev;
+    long long t[16];
+    __device__ __forceinline__ void start() { if (on) prev = clock64(); }
+    __device__ __forceinline__ void mark(int k) {
+        if (on && k >= 0) {
+            long long now = clock64();
+            t[k] += now - prev;
+            prev = now;
+        }
+    }
+};
+#define SC_STAMP_ARG , Stamp &stampv, int sk0
+#define SC_STAMP_PASS(k) , stampv, (k)
+#define SC_MARK(k) stampv.mark(k)
+#else
+#define SC_STAMP_ARG
+#define SC_STAMP_PASS(k)
+#define SC_MARK(k)
+#endif
+
 // GEMM pixel (tile pt, lane-in-tile i) -> board pixel (rank*8 + file); see the header comment
 __device__ inline int gpix2board(int pt, int i) {
     const bool inA = (i < 4) || (i >= 12 && i < 16) || (i >= 20 && i < 28);
@@ -44,6 +68,14 @@ __device__ __forceinline__ void ch_load(ChP<CT>& P, const float* __restrict__ p,
     for (int ct = 0; ct < CT; ct++)
 #pragma unroll
         for (int g = 0; g < 4; g++) P.v[ct][g] = *reinterpret_cast<const f32x4*>(p + chan32<CT>(wave, ct, g, h));
+}
+// same, from a parameter array staged in LDS (byte offset inside g_smem)
+template <int CT>
+__device__ __forceinline__ void ch_load_lds(ChP<CT>& P, int byte_off, int wave, int h) {
+#pragma unroll
+    for (int ct = 0; ct < CT; ct++)
+#pragma unroll
+        for (int g = 0; g < 4; g++) P.v[ct][g] = *reinterpret_cast<const f32x4*>(g_smem + byte_off + chan32<CT>(wave, ct, g, h) * 4);
 }
 // the conv bias is the accumulator's initial value
 template <int CT>
@@ -146,11 +178,16 @@ __device__ __forceinline__ void conv_mma32(int xoff, const bf16_t* __restrict__ 
 }
 
 // LayerNorm over `count` channels (eps 1e-6, timm LayerNorm2d) + optional ReLU, in place; the bias is already in
-// the accumulators.  s_stat2: two alternating [4 waves][64 pixels] float2 buffers (one barrier per LayerNorm, as
-// in bias_layernorm).  Pixels are indexed by GEMM pixel (pt*32 + lane&31).
+// the accumulators.  Two halves: ln_reduce (per-pixel statistics: in-register sums, one lane^32 exchange, one LDS
+// exchange between the 4 waves, ONE barrier) and ln_apply.  s_stat2: two alternating [4 waves][64 pixels] float2
+// buffers: the buffer written here was last read two LayerNorms ago, and every wave has passed the barrier of the
+// LayerNorm in between since then.  Pixels are indexed by GEMM pixel (pt*32 + lane&31).
+struct LnStat {
+    float rstd[2], nm[2];   // per pixel tile: 1/sigma and -mean/sigma
+};
 template <int CT>
-__device__ inline void layernorm32(f32x16 (&acc)[CT][2], const ChP<CT>& G, const ChP<CT>& E, int count, bool relu, int wave,
-                                   int lane, float* s_stat2, int& parity) {
+__device__ inline void ln_reduce(const f32x16 (&acc)[CT][2], LnStat& L, int count, int wave, int lane, float* s_stat2,
+                                 int& parity SC_STAMP_ARG) {
     float2* st = reinterpret_cast<float2*>(s_stat2) + (parity & 1) * 256;
     parity ^= 1;
     const int i = lane & 31;
@@ -173,7 +210,9 @@ __device__ inline void layernorm32(f32x16 (&acc)[CT][2], const ChP<CT>& G, const
         st[wave * 64 + i] = make_float2(s[0], q[0]);
         st[wave * 64 + 32 + i] = make_float2(s[1], q[1]);
     }
+    SC_MARK(sk0);
     __syncthreads();
+    SC_MARK(sk0 + 1);
     const float inv = 1.0f / (float)count;
 #pragma unroll
     for (int pt = 0; pt < 2; pt++) {
@@ -184,17 +223,30 @@ __device__ inline void layernorm32(f32x16 (&acc)[CT][2], const ChP<CT>& G, const
         float mean = S * inv;
         float var = Q * inv - mean * mean;
         var = var < 0.f ? 0.f : var;
-        float rstd = 1.0f / sqrtf(var + 1e-6f);
-        float nm = -mean * rstd;
+        L.rstd[pt] = 1.0f / sqrtf(var + 1e-6f);
+        L.nm[pt] = -mean * L.rstd[pt];
+    }
+}
+template <int CT>
+__device__ __forceinline__ void ln_apply(f32x16 (&acc)[CT][2], const LnStat& L, const ChP<CT>& G, const ChP<CT>& E, bool relu) {
+#pragma unroll
+    for (int pt = 0; pt < 2; pt++)
 #pragma unroll
         for (int ct = 0; ct < CT; ct++)
 #pragma unroll
             for (int r = 0; r < 16; r++) {
-                float t = acc[ct][pt][r] * rstd + nm;
+                float t = acc[ct][pt][r] * L.rstd[pt] + L.nm[pt];
                 float y = t * G.v[ct][r >> 2][r & 3] + E.v[ct][r >> 2][r & 3];
                 acc[ct][pt][r] = (relu && y < 0.f) ? 0.f : y;
             }
-    }
+}
+// parameters already in registers (stem, heads)
+template <int CT>
+__device__ inline void layernorm32(f32x16 (&acc)[CT][2], const ChP<CT>& G, const ChP<CT>& E, int count, bool relu, int wave,
+                                   int lane, float* s_stat2, int& parity SC_STAMP_ARG) {
+    LnStat L;
+    ln_reduce<CT>(acc, L, count, wave, lane, s_stat2, parity SC_STAMP_PASS(sk0));
+    ln_apply<CT>(acc, L, G, E, relu);
 }
 
 // accumulators -> bf16 image: pixbase[pt] = byte offset of the lane's pixel row inside g_smem, 4 adjacent channels
@@ -214,28 +266,56 @@ __device__ inline void store_image32(const f32x16 (&acc)[CT][2], const int (&pix
             }
 }
 
-// one level of the halving butterfly over the 32 lanes of a half-wave: lanes with BIT set keep the upper W values
-// (W = 0: a single value is left, plain exchange-add)
-template <int NV, int W, int BIT>
+// Halving butterfly over the 32 lanes of a half-wave (squeeze-excitation average pool).  Level LVL pairs every lane
+// with a partner whose bit (16 >> LVL) differs: lane^16 through the LDS crossbar, then lane^15 (row_mirror),
+// lane^7 (row_half_mirror), lane^2 and lane^1 (quad_perm) as DPP moves -- five independent XOR masks, so every
+// lane's contribution reaches every sum exactly once.  Lanes with the bit set keep the upper W values (W = 0: a
+// single value is left, plain exchange-add).  Lane j of a half ends with value index j (32 values) or j>>1 (16).
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, false));
+}
+template <int LVL>
+__device__ __forceinline__ float pool_xchg(float x) {
+    if constexpr (LVL == 0) return __shfl_xor(x, 16, 64);
+    else if constexpr (LVL == 1) return dpp_mov<0x140>(x);   // row_mirror
+    else if constexpr (LVL == 2) return dpp_mov<0x141>(x);   // row_half_mirror
+    else if constexpr (LVL == 3) return dpp_mov<0x4E>(x);    // quad_perm [2,3,0,1]
+    else return dpp_mov<0xB1>(x);                            // quad_perm [1,0,3,2]
+}
+template <int NV, int W, int LVL>
 __device__ __forceinline__ void pool_level(float (&v)[NV], int lane) {
-    if constexpr (W >= 1) {
-        const bool hi = (lane & BIT) != 0;
+    if constexpr (LVL < 5) {
+        if constexpr (W >= 1) {
+            const bool hi = (lane & (16 >> LVL)) != 0;
 #pragma unroll
-        for (int t = 0; t < W; t++) {
-            float send = hi ? v[t] : v[t + W], keep = hi ? v[t + W] : v[t];
-            v[t] = keep + __shfl_xor(send, BIT, 64);
+            for (int t = 0; t < W; t++) {
+                float send = hi ? v[t] : v[t + W], keep = hi ? v[t + W] : v[t];
+                v[t] = keep + pool_xchg<LVL>(send);
+            }
+            pool_level<NV, W / 2, LVL + 1>(v, lane);
+        } else {
+            v[0] += pool_xchg<LVL>(v[0]);
+            pool_level<NV, 0, LVL + 1>(v, lane);
         }
-        pool_level<NV, W / 2, BIT / 2>(v, lane);
-    } else if constexpr (BIT >= 1) {
-        v[0] += __shfl_xor(v[0], BIT, 64);
-        pool_level<NV, 0, BIT / 2>(v, lane);
     }
+}
+
+// first RS-1 k-steps of a layer's weights into its ring, ahead of the conv_mma32<.., PRE = true> that consumes them
+template <int CT, int TILES, int RS>
+__device__ __forceinline__ void ring_fill(bf16x8 (&bq)[RS][CT], const bf16_t* __restrict__ Wp, int wave_u, int lane) {
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<bf16_t*>(Wp) + (size_t)wave_u * CT * 512, 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+    for (int st = 0; st < RS - 1; st++)
+#pragma unroll
+        for (int ct = 0; ct < CT; ct++) bq[st][ct] = wload(rsrc, lane * 16 + ct * 1024, st * TILES * 1024);
 }
 
 constexpr int tower32_lds_bytes(int C) {
     const int xa = 100 * (C + 8) * 2;
     const int r1 = 64 * (C + 4) * 4, r2 = 64 * (HEAD + 8) * 2;
-    return xa + (r1 > r2 ? r1 : r2) + 4096 + 3072 + 1024 + 64;
+    return xa + (r1 > r2 ? r1 : r2) + 4096 + 3072 + 1024 + 64 + 15 * C * 2;
 }
 
 template <int C, int RS, int TPI>
@@ -255,6 +335,7 @@ __global__ __launch_bounds__(256, 1) void k_tower32(TowerArgs A) {
     float* s_vec = s_stat + 1024;                                           // SE vectors (packed bf16)
     float* s_scl = s_vec + 768;                                             // [C] SE scales
     float* s_red = s_scl + 256;                                             // [8]
+    constexpr int PAR_OFF = XA_BYTES + RS_BYTES + 4096 + 3072 + 1024 + 64;  // staged per-block parameters, 7.5*C floats
     bf16_t* s_xb = reinterpret_cast<bf16_t*>(s_vec);
     float* s_z = reinterpret_cast<float*>(smem);                            // policy logits [4672], aliases Xa (after the trunk)
     static_assert(4672 * 4 <= XA_BYTES, "policy logits must fit in the image area");
@@ -316,6 +397,13 @@ __global__ __launch_bounds__(256, 1) void k_tower32(TowerArgs A) {
         }
     };
 
+#ifdef SC_EXP
+    Stamp stampv;
+    stampv.on = A.dbg && A.dbg_stage == 2000 && lane == 0;
+    stampv.prev = 0;
+    for (int k = 0; k < 16; k++) stampv.t[k] = 0;
+    stampv.start();
+#endif
     bf16x8 ring[RS][CT];   // weight prefetch ring, carried from layer to layer
     ChP<CT> Bn;            // bias of the NEXT conv (requested one epilogue early)
     // ---- conv_block (py/module.py:120-126): conv3x3 112->C (K padded to 128/tap), LN, ReLU
@@ -330,49 +418,57 @@ __global__ __launch_bounds__(256, 1) void k_tower32(TowerArgs A) {
         ch_load<CT>(E, f + 2 * C, wave, h);
         ch_load<CT>(Bn, net.wf + net.f_blocks, wave, h);
         __builtin_amdgcn_sched_barrier(0);
-        layernorm32<CT>(acc, G, E, C, true, wave, lane, s_stat, ln_parity);
+        layernorm32<CT>(acc, G, E, C, true, wave, lane, s_stat, ln_parity SC_STAMP_PASS(-2));
     }
     store_res();
     store_image32<CT>(acc, pixbase, wave, h);  // every wave passed the LN barrier: the input image is dead
     __syncthreads();
+    SC_MARK(14);
     dump(0);
 
-    // developer aid: dbg_stage 2000 -> cycle stamps (summed over blocks) of the block's phases in dbg[pos][0..7]
-    const bool stamp = A.dbg && A.dbg_stage == 2000 && tid == 0;
-    long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    long long tprev = 0;
-    auto mark = [&](int k) {
-        if (stamp) {
-            long long t = clock64();
-            tacc[k] += t - tprev;
-            tprev = t;
-        }
-    };
     // ---- residual tower (ResBlockSE.forward, py/module.py:38-46)
 #pragma unroll 1
     for (int b = 0; b < net.n_blocks; b++) {
         const bf16_t* wb = net.wb + net.o_blocks + (size_t)b * net.blk_stride_b;
         const float* wf = net.wf + net.f_blocks + (size_t)b * net.blk_stride_f;
         constexpr int NT1 = C / 32;                       // 16-column tiles of SE fc1
-        constexpr bool FULL1 = (C == 128);
-        constexpr int NTW1 = FULL1 ? NT1 : NT1 / 4;
-        constexpr int PW1 = NT1 / 4;                      // fc1 tiles per wave in the packed column order
-        if (stamp) tprev = clock64();
-        // conv1 -> LN -> ReLU.  Per-channel parameters are requested right after the loop that precedes their use.
+        constexpr int NTW1 = NT1 / 4;
+        // The block's per-channel parameters -- everything from conv1's LayerNorm to the NEXT block's conv1 bias,
+        // 7.5*C contiguous floats -- are fetched cooperatively (one or two 16-byte loads per thread) under conv1 and
+        // staged in LDS behind conv1's LayerNorm barrier: per-lane parameter fetches straight from L2 cost a full
+        // 1 KiB wave-load through the texture path each, on the critical path of every epilogue.
+        constexpr int PAR_V4 = 15 * C / 8;                // float4 count of the window
+        constexpr int NPV = (PAR_V4 + 255) / 256;
+        constexpr int P_G1 = PAR_OFF, P_E1 = PAR_OFF + 4 * C, P_B2 = PAR_OFF + 8 * C, P_G2 = PAR_OFF + 12 * C, P_E2 = PAR_OFF + 16 * C;
+        constexpr int P_SB1 = PAR_OFF + 20 * C, P_SB2 = PAR_OFF + 22 * C, P_BN = PAR_OFF + 26 * C;
+#ifdef SC_EXP
+        stampv.start();
+#endif
+        f32x4 pv[NPV];
+#pragma unroll
+        for (int k = 0; k < NPV; k++)
+            if (tid + 256 * k < PAR_V4) pv[k] = *reinterpret_cast<const f32x4*>(wf + C + (size_t)(tid + 256 * k) * 4);
+        __builtin_amdgcn_sched_barrier(0);
+        // conv1 -> LN -> ReLU
         acc_init<CT>(acc, Bn);
         conv_mma32<C, 9, CT, TILES, CP, RS, TPI, true>(0, wb, wave, lane, px, acc, ring, 9 * C * C * 2);
-        mark(0);
+        SC_MARK(0);
+#pragma unroll
+        for (int k = 0; k < NPV; k++)
+            if (tid + 256 * k < PAR_V4) *reinterpret_cast<f32x4*>(g_smem + PAR_OFF + (tid + 256 * k) * 16) = pv[k];
         {
+            LnStat L;
+            ln_reduce<CT>(acc, L, C, wave, lane, s_stat, ln_parity SC_STAMP_PASS(1));   // its barrier publishes the parameters
             ChP<CT> G, E;
-            ch_load<CT>(G, wf + C, wave, h);
-            ch_load<CT>(E, wf + 2 * C, wave, h);
-            ch_load<CT>(Bn, wf + 3 * C, wave, h);
-            __builtin_amdgcn_sched_barrier(0);
-            layernorm32<CT>(acc, G, E, C, true, wave, lane, s_stat, ln_parity);
+            ch_load_lds<CT>(G, P_G1, wave, h);
+            ch_load_lds<CT>(E, P_E1, wave, h);
+            ln_apply<CT>(acc, L, G, E, true);
         }
+        SC_MARK(3);
         store_image32<CT>(acc, pixbase, wave, h);
+        ch_load_lds<CT>(Bn, P_B2, wave, h);
         __syncthreads();
-        mark(1);
+        SC_MARK(4);
         // conv2 -> LN
         acc_init<CT>(acc, Bn);
         {
@@ -380,34 +476,23 @@ __global__ __launch_bounds__(256, 1) void k_tower32(TowerArgs A) {
             const int nxt = (b + 1 < net.n_blocks) ? (int)(net.blk_stride_b - (size_t)9 * C * C) * 2 : 0;
             conv_mma32<C, 9, CT, TILES, CP, RS, TPI, true>(0, wb + (size_t)9 * C * C, wave, lane, px, acc, ring, nxt);
         }
-        mark(2);
-        // squeeze-excitation weights and all remaining parameters of the block are requested now: their L2 round
-        // trip hides under the LayerNorm.  Narrow trunk: every wave computes the whole C -> C/2 layer itself.
+        SC_MARK(5);
+        // squeeze-excitation weights are requested now: their L2 round trip hides under the LayerNorm.  The columns
+        // of both layers are split over the 4 waves.
         VecW<C, NTW1> w1;
         VecW<C / 2, NTW> w2;
-        float b1v[NTW1], b2v[NTW];
+        vec_w_load<C, NTW1, NT1>(w1, wb + (size_t)18 * C * C, wave * NTW1, lane);
+        vec_w_load<C / 2, NTW, C / 16>(w2, wb + (size_t)18 * C * C + (size_t)C * (C / 2), wave * NTW, lane);
+        __builtin_amdgcn_sched_barrier(0);
         {
+            LnStat L;
+            ln_reduce<CT>(acc, L, C, wave, lane, s_stat, ln_parity SC_STAMP_PASS(6));
             ChP<CT> G, E;
-            ch_load<CT>(G, wf + 4 * C, wave, h);
-            ch_load<CT>(E, wf + 5 * C, wave, h);
-            ch_load<CT>(Bn, (b + 1 < net.n_blocks) ? wf + net.blk_stride_f : wf, wave, h);
-            vec_w_load<C, NTW1, NT1>(w1, wb + (size_t)18 * C * C, FULL1 ? 0 : wave * NTW1, lane);
-            vec_w_load<C / 2, NTW, C / 16>(w2, wb + (size_t)18 * C * C + (size_t)C * (C / 2), wave * NTW, lane);
-            const float* b1 = wf + 6 * C;
-            const float* b2 = wf + 6 * C + C / 2;
-            const int c0 = chan0<NTW>(wave, lane);
-#pragma unroll
-            for (int k = 0; k < NTW1; k++) {
-                // packed column (tile, lane) -> hidden channel: tiles were laid out for a 4-wave split
-                const int tile = FULL1 ? k : wave * NTW1 + k;
-                b1v[k] = b1[(tile / PW1) * (16 * PW1) + (lane & 15) * PW1 + (tile % PW1)];
-            }
-#pragma unroll
-            for (int k = 0; k < NTW; k++) b2v[k] = b2[c0 + k];
-            __builtin_amdgcn_sched_barrier(0);
-            layernorm32<CT>(acc, G, E, C, false, wave, lane, s_stat, ln_parity);
+            ch_load_lds<CT>(G, P_G2, wave, h);
+            ch_load_lds<CT>(E, P_E2, wave, h);
+            ln_apply<CT>(acc, L, G, E, false);
         }
-        mark(3);
+        SC_MARK(8);
         // global average pool over the 64 pixels: in-lane over the two tiles, then a halving butterfly over the
         // 32 lanes of a half-wave (lane j of a half ends up with register index j, or j>>1 when there are 16)
         {
@@ -417,12 +502,14 @@ __global__ __launch_bounds__(256, 1) void k_tower32(TowerArgs A) {
             for (int ct = 0; ct < CT; ct++)
 #pragma unroll
                 for (int r = 0; r < 16; r++) v[ct * 16 + r] = acc[ct][0][r] + acc[ct][1][r];
-            pool_level<NV, NV / 2, 16>(v, lane);
+            pool_level<NV, NV / 2, 0>(v, lane);
             const int idx = (NV == 32) ? i32 : (i32 >> 1);
             s_xb[chan32<CT>(wave, idx >> 4, (idx & 15) >> 2, h) + (idx & 3)] = f2bf(v[0] * (1.0f / 64.0f));  // conv inputs are bf16 (autocast)
         }
+        SC_MARK(9);
         __syncthreads();
-        bf16_t* s_hid = s_xb + 256 + (FULL1 ? wave * 128 : 0);   // hidden vector (wave-private when FULL1)
+        SC_MARK(10);
+        bf16_t* s_hid = s_xb + 256;                              // hidden vector
         {
             // fc1: C -> C/2, ReLU
             f32x4 hh[NTW1];
@@ -432,14 +519,14 @@ __global__ __launch_bounds__(256, 1) void k_tower32(TowerArgs A) {
             if (lane < 16) {
 #pragma unroll
                 for (int k = 0; k < NTW1; k++) {
-                    const int tile = FULL1 ? k : wave * NTW1 + k;
-                    const int j = (tile / PW1) * (16 * PW1) + (lane & 15) * PW1 + (tile % PW1);
-                    float t = hh[k][0] + b1v[k];
+                    // packed column (tile, lane) -> hidden channel ("lane owns NTW1 adjacent channels" order)
+                    const int j = wave * (16 * NTW1) + (lane & 15) * NTW1 + k;
+                    float t = hh[k][0] + *reinterpret_cast<const float*>(g_smem + P_SB1 + j * 4);
                     s_hid[j] = f2bf(t > 0.f ? t : 0.f);
                 }
             }
         }
-        if (!FULL1) __syncthreads();  // FULL1: the hidden vector is wave-private (DS ops of a wave execute in order)
+        __syncthreads();
         {
             // fc2: C/2 -> C, sigmoid; every wave produces the scales of exactly its own channels and hands them to
             // its lanes through LDS (wave-private, no barrier)
@@ -450,10 +537,11 @@ __global__ __launch_bounds__(256, 1) void k_tower32(TowerArgs A) {
             if (lane < 16) {
                 const int c0 = chan0<NTW>(wave, lane);
 #pragma unroll
-                for (int k = 0; k < NTW; k++) s_scl[c0 + k] = 1.0f / (1.0f + __expf(-(sc[k][0] + b2v[k])));
+                for (int k = 0; k < NTW; k++)
+                    s_scl[c0 + k] = 1.0f / (1.0f + __expf(-(sc[k][0] + *reinterpret_cast<const float*>(g_smem + P_SB2 + (c0 + k) * 4))));
             }
         }
-        mark(4);
+        SC_MARK(11);
 #pragma unroll
         for (int ct = 0; ct < CT; ct++)
 #pragma unroll
@@ -472,26 +560,59 @@ __global__ __launch_bounds__(256, 1) void k_tower32(TowerArgs A) {
             }
         store_res();                               // each lane rewrites exactly the cells it just read
         store_image32<CT>(acc, pixbase, wave, h);  // conv2 finished reading Xa before the SE barriers
+        ch_load_lds<CT>(Bn, P_BN, wave, h);        // next block's conv1 bias: read before the barrier that frees the staging area
+        SC_MARK(12);
         __syncthreads();
-        mark(5);
+        SC_MARK(13);
         dump(b + 1);
     }
     dump(1000);
-    if (stamp) tprev = clock64();
+#ifdef SC_EXP
+    stampv.start();
+#endif
 
     const int gpb[2] = {(i32 * HP) * 2, ((32 + i32) * HP) * 2};   // rows of the plain (non-haloed) policy image
+    // The three heads' per-channel parameters (1920 contiguous floats) are fetched cooperatively under the value
+    // conv and staged in LDS (the SE scratch is dead now), like the per-block parameters of the trunk.
+    constexpr int HPAR = XA_BYTES + RS_BYTES + 4096;            // byte offset of the staging area (s_vec ...)
+    constexpr int HP_V = HPAR, HP_P1 = HPAR + 3 * HEAD * 4, HP_P2 = HPAR + 6 * HEAD * 4;
+    static_assert(6 * HEAD * 4 + 3 * POL_PAD * 4 <= 3072 + 1024 + 64 + 15 * C * 2, "head parameters must fit in the staging area");
+    f32x4 hpv[2];
+#pragma unroll
+    for (int k = 0; k < 2; k++)
+        if (tid + 256 * k < 480) hpv[k] = *reinterpret_cast<const f32x4*>(net.wf + net.f_vhead + (size_t)(tid + 256 * k) * 4);
+    __builtin_amdgcn_sched_barrier(0);
+    bf16x8 hr[4][2];      // weight ring of the 256-wide head convs
+    bf16x8 hr2[4][1];     // ... of the 73-wide one
     // ---- value head conv (py/module.py:89-94): conv1x1 C->256, LN, ReLU -> bf16 features in HBM
     {
-        const float* f = net.wf + net.f_vhead;
-        ChP<2> Bv, G, E;
-        ch_load<2>(Bv, f, wave, h);
-        ch_load<2>(G, f + HEAD, wave, h);
-        ch_load<2>(E, f + 2 * HEAD, wave, h);
         f32x16 hv[2][2];
-        acc_init<2>(hv, Bv);
-        bf16x8 hr[4][2];
+#pragma unroll
+        for (int ct = 0; ct < 2; ct++)
+#pragma unroll
+            for (int pt = 0; pt < 2; pt++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) hv[ct][pt][r] = 0.f;
         conv_mma32<C, 1, 2, 8, CP, 4, 1, false>(0, net.wb + net.o_vconv, wave, lane, px, hv, hr, 0);
-        layernorm32<2>(hv, G, E, HEAD, true, wave, lane, s_stat, ln_parity);
+#pragma unroll
+        for (int k = 0; k < 2; k++)
+            if (tid + 256 * k < 480) *reinterpret_cast<f32x4*>(g_smem + HPAR + (tid + 256 * k) * 16) = hpv[k];
+        ring_fill<2, 8, 4>(hr, net.wb + net.o_pconv1, wave, lane);   // policy conv1's first weights: hidden under the LN
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        ChP<2> Bv, G, E;
+        ch_load_lds<2>(Bv, HP_V, wave, h);
+#pragma unroll
+        for (int ct = 0; ct < 2; ct++)
+#pragma unroll
+            for (int pt = 0; pt < 2; pt++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) hv[ct][pt][r] += Bv.v[ct][r >> 2][r & 3];
+        LnStat L;
+        ln_reduce<2>(hv, L, HEAD, wave, lane, s_stat, ln_parity SC_STAMP_PASS(-2));
+        ch_load_lds<2>(G, HP_V + HEAD * 4, wave, h);
+        ch_load_lds<2>(E, HP_V + 2 * HEAD * 4, wave, h);
+        ln_apply<2>(hv, L, G, E, true);
 #pragma unroll
         for (int ct = 0; ct < 2; ct++)
 #pragma unroll
@@ -506,33 +627,35 @@ __global__ __launch_bounds__(256, 1) void k_tower32(TowerArgs A) {
     }
     // ---- policy head (py/module.py:70-76): conv1x1 C->256, LN, conv1x1 256->73, LN (no ReLU between)
     {
-        const float* f = net.wf + net.f_phead1;
         ChP<2> Bv, G, E;
-        ch_load<2>(Bv, f, wave, h);
-        ch_load<2>(G, f + HEAD, wave, h);
-        ch_load<2>(E, f + 2 * HEAD, wave, h);
+        ch_load_lds<2>(Bv, HP_P1, wave, h);
         f32x16 hp[2][2];
         acc_init<2>(hp, Bv);
-        bf16x8 hr[4][2];
-        conv_mma32<C, 1, 2, 8, CP, 4, 1, false>(0, net.wb + net.o_pconv1, wave, lane, px, hp, hr, 0);
-        layernorm32<2>(hp, G, E, HEAD, false, wave, lane, s_stat, ln_parity);
+        conv_mma32<C, 1, 2, 8, CP, 4, 1, true>(0, net.wb + net.o_pconv1, wave, lane, px, hp, hr, 0);
+        ring_fill<1, 4, 4>(hr2, net.wb + net.o_pconv2, wave, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        LnStat L;
+        ln_reduce<2>(hp, L, HEAD, wave, lane, s_stat, ln_parity SC_STAMP_PASS(-2));
+        ch_load_lds<2>(G, HP_P1 + HEAD * 4, wave, h);
+        ch_load_lds<2>(E, HP_P1 + 2 * HEAD * 4, wave, h);
+        ln_apply<2>(hp, L, G, E, false);
         const int xb[2] = {XA_BYTES + gpb[0], XA_BYTES + gpb[1]};
         store_image32<2>(hp, xb, wave, h);   // Xh aliases the residual area (dead after the trunk)
     }
     __syncthreads();
     {
-        const float* f = net.wf + net.f_phead2;
         ChP<1> Bv, G, E;
-        ch_load<1>(Bv, f, wave, h);
-        ch_load<1>(G, f + POL_PAD, wave, h);
-        ch_load<1>(E, f + 2 * POL_PAD, wave, h);
+        ch_load_lds<1>(Bv, HP_P2, wave, h);
         f32x16 z[1][2];
         acc_init<1>(z, Bv);
-        bf16x8 hr[4][1];
         const int pxh[2] = {gpb[0] + h * 16, gpb[1] + h * 16};
-        conv_mma32<HEAD, 1, 1, 4, HP, 4, 1, false>(XA_BYTES, net.wb + net.o_pconv2, wave, lane, pxh, z, hr, 0);
+        conv_mma32<HEAD, 1, 1, 4, HP, 4, 1, true>(XA_BYTES, net.wb + net.o_pconv2, wave, lane, pxh, z, hr2, 0);
         // padded channels (>=73) have zero weights, bias, gamma, beta: they add 0 to both LN sums
-        layernorm32<1>(z, G, E, 73, false, wave, lane, s_stat, ln_parity);
+        LnStat L;
+        ln_reduce<1>(z, L, 73, wave, lane, s_stat, ln_parity SC_STAMP_PASS(-2));
+        ch_load_lds<1>(G, HP_P2 + POL_PAD * 4, wave, h);
+        ch_load_lds<1>(E, HP_P2 + 2 * POL_PAD * 4, wave, h);
+        ln_apply<1>(z, L, G, E, false);
         __syncthreads();  // everyone is done with Xa/Xh: the logits may overwrite the image area
 #pragma unroll
         for (int pt = 0; pt < 2; pt++)
@@ -574,10 +697,11 @@ __global__ __launch_bounds__(256, 1) void k_tower32(TowerArgs A) {
         s = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]) + 1e-5f;  // post_process_distr (chess.rs:891)
         if (tid < n) A.prior[(size_t)pos * 224 + tid] = e / s;
     }
-    if (stamp) {
-        mark(6);
-        for (int k = 0; k < 8; k++) A.dbg[(size_t)pos * 64 * C + k] = (float)tacc[k];
-    }
+#ifdef SC_EXP
+    SC_MARK(15);
+    if (stampv.on)
+        for (int k = 0; k < 16; k++) A.dbg[(size_t)pos * 64 * C + wave * 16 + k] = (float)stampv.t[k];
+#endif
 }
 
 }  // namespace scnn

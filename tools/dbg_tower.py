@@ -1,3 +1,5 @@
+"""developer tool: per-wave phase stamps of the tower (needs the experiment build: tools/build_exp.sh, then
+SC_ENGINE_LIB=smart-chess-rust_amd/lib_exp/libsc_engine.so python tools/dbg_tower.py)"""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -6,13 +8,16 @@ import scamd
 g = np.load(os.path.join(ROOT, "tests", "golden", "nn_ref_b10_c256.npz"))
 boards = np.repeat(g["boards"], 32, axis=0)[:256]
 meta = np.repeat(g["meta"], 32, axis=0)[:256]
-names = ["conv1", "LN1+store", "conv2", "LN2(+SE w loads)", "pool+SE", "resid+store", "heads"]
+names = ["conv1", "LN1 stats", "LN1 barrier", "LN1 norm", "store+barrier", "conv2", "LN2 stats", "LN2 barrier", "LN2 norm",
+         "pool", "pool barrier", "fc1+fc2", "resid+stores", "end barrier", "prologue+stem", "heads"]
 for C in (128, 256):
     eng = scamd.Engine(10, C, seed=1)
     for _ in range(3):
         d = eng.debug(boards, meta, 2000)
-    t = d[:, 0, :8].astype(np.float64)   # [pos][8]
-    med = np.median(t, axis=0)
-    tot = med[:7].sum()
-    print(f"C={C}: total stamped {tot:.0f} cycles  " + "  ".join(f"{n}={v:.0f} ({100*v/tot:.0f}%)" for n, v in zip(names, med)))
+    t = d[:, 0, :64].astype(np.float64).reshape(-1, 4, 16)   # [pos][wave][16]
+    med = np.median(t, axis=0)                                  # [wave][16]
+    tot = med[0].sum()
+    print(f"C={C}: wave-0 total {tot:.0f} cycles", flush=True)
+    for k, n in enumerate(names):
+        print(f"   {n:14s} " + "  ".join(f"{med[w, k]:8.0f}" for w in range(4)) + f"   ({100 * med[:, k].mean() / tot:.1f}%)")
     eng.close()
