@@ -185,9 +185,12 @@ __device__ __forceinline__ void conv_mma32(int xoff, const bf16_t* __restrict__ 
 struct LnStat {
     float rstd[2], nm[2];   // per pixel tile: 1/sigma and -mean/sigma
 };
+// ReLU is a single v_max_f32 (which maps NaN to 0, unlike torch.relu): a NaN anywhere in the network reaches some
+// LayerNorm's variance first, so ln_reduce records it in `bad` and the kernel poisons its outputs at the end --
+// non-finite results stay visible to the caller (reference: warning at src/backends/torch.rs:129-135).
 template <int CT>
 __device__ inline void ln_reduce(const f32x16 (&acc)[CT][2], LnStat& L, int count, int wave, int lane, float* s_stat2,
-                                 int& parity SC_STAMP_ARG) {
+                                 int& parity, int& bad SC_STAMP_ARG) {
     float2* st = reinterpret_cast<float2*>(s_stat2) + (parity & 1) * 256;
     parity ^= 1;
     const int i = lane & 31;
@@ -222,8 +225,9 @@ __device__ inline void ln_reduce(const f32x16 (&acc)[CT][2], LnStat& L, int coun
         float Q = (a0.y + a1.y) + (a2.y + a3.y);
         float mean = S * inv;
         float var = Q * inv - mean * mean;
-        var = var < 0.f ? 0.f : var;
-        L.rstd[pt] = 1.0f / sqrtf(var + 1e-6f);
+        bad |= (var != var) ? 1 : 0;
+        var = fmaxf(var, 0.f);
+        L.rstd[pt] = __frsqrt_rn(var + 1e-6f);
         L.nm[pt] = -mean * L.rstd[pt];
     }
 }
@@ -237,15 +241,15 @@ __device__ __forceinline__ void ln_apply(f32x16 (&acc)[CT][2], const LnStat& L, 
             for (int r = 0; r < 16; r++) {
                 float t = acc[ct][pt][r] * L.rstd[pt] + L.nm[pt];
                 float y = t * G.v[ct][r >> 2][r & 3] + E.v[ct][r >> 2][r & 3];
-                acc[ct][pt][r] = (relu && y < 0.f) ? 0.f : y;
+                acc[ct][pt][r] = relu ? fmaxf(y, 0.f) : y;
             }
 }
 // parameters already in registers (stem, heads)
 template <int CT>
 __device__ inline void layernorm32(f32x16 (&acc)[CT][2], const ChP<CT>& G, const ChP<CT>& E, int count, bool relu, int wave,
-                                   int lane, float* s_stat2, int& parity SC_STAMP_ARG) {
+                                   int lane, float* s_stat2, int& parity, int& bad SC_STAMP_ARG) {
     LnStat L;
-    ln_reduce<CT>(acc, L, count, wave, lane, s_stat2, parity SC_STAMP_PASS(sk0));
+    ln_reduce<CT>(acc, L, count, wave, lane, s_stat2, parity, bad SC_STAMP_PASS(sk0));
     ln_apply<CT>(acc, L, G, E, relu);
 }
 
@@ -375,6 +379,7 @@ __global__ __launch_bounds__(256, 1) void k_tower32(TowerArgs A) {
 
     f32x16 acc[CT][2];
     int ln_parity = 0;
+    int bad = 0;   // a LayerNorm saw a NaN variance
     auto store_res = [&]() {
 #pragma unroll
         for (int ct = 0; ct < CT; ct++)
@@ -418,7 +423,7 @@ __global__ __launch_bounds__(256, 1) void k_tower32(TowerArgs A) {
         ch_load<CT>(E, f + 2 * C, wave, h);
         ch_load<CT>(Bn, net.wf + net.f_blocks, wave, h);
         __builtin_amdgcn_sched_barrier(0);
-        layernorm32<CT>(acc, G, E, C, true, wave, lane, s_stat, ln_parity SC_STAMP_PASS(-2));
+        layernorm32<CT>(acc, G, E, C, true, wave, lane, s_stat, ln_parity, bad SC_STAMP_PASS(-2));
     }
     store_res();
     store_image32<CT>(acc, pixbase, wave, h);  // every wave passed the LN barrier: the input image is dead
@@ -458,7 +463,7 @@ __global__ __launch_bounds__(256, 1) void k_tower32(TowerArgs A) {
             if (tid + 256 * k < PAR_V4) *reinterpret_cast<f32x4*>(g_smem + PAR_OFF + (tid + 256 * k) * 16) = pv[k];
         {
             LnStat L;
-            ln_reduce<CT>(acc, L, C, wave, lane, s_stat, ln_parity SC_STAMP_PASS(1));   // its barrier publishes the parameters
+            ln_reduce<CT>(acc, L, C, wave, lane, s_stat, ln_parity, bad SC_STAMP_PASS(1));   // its barrier publishes the parameters
             ChP<CT> G, E;
             ch_load_lds<CT>(G, P_G1, wave, h);
             ch_load_lds<CT>(E, P_E1, wave, h);
@@ -486,7 +491,7 @@ __global__ __launch_bounds__(256, 1) void k_tower32(TowerArgs A) {
         __builtin_amdgcn_sched_barrier(0);
         {
             LnStat L;
-            ln_reduce<CT>(acc, L, C, wave, lane, s_stat, ln_parity SC_STAMP_PASS(6));
+            ln_reduce<CT>(acc, L, C, wave, lane, s_stat, ln_parity, bad SC_STAMP_PASS(6));
             ChP<CT> G, E;
             ch_load_lds<CT>(G, P_G2, wave, h);
             ch_load_lds<CT>(E, P_E2, wave, h);
@@ -522,7 +527,7 @@ __global__ __launch_bounds__(256, 1) void k_tower32(TowerArgs A) {
                     // packed column (tile, lane) -> hidden channel ("lane owns NTW1 adjacent channels" order)
                     const int j = wave * (16 * NTW1) + (lane & 15) * NTW1 + k;
                     float t = hh[k][0] + *reinterpret_cast<const float*>(g_smem + P_SB1 + j * 4);
-                    s_hid[j] = f2bf(t > 0.f ? t : 0.f);
+                    s_hid[j] = f2bf(fmaxf(t, 0.f));
                 }
             }
         }
@@ -554,7 +559,7 @@ __global__ __launch_bounds__(256, 1) void k_tower32(TowerArgs A) {
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
                         float y = acc[ct][pt][4 * g + k] * sv[k] + rv[k];
-                        acc[ct][pt][4 * g + k] = y > 0.f ? y : 0.f;
+                        acc[ct][pt][4 * g + k] = fmaxf(y, 0.f);
                     }
                 }
             }
@@ -609,7 +614,7 @@ __global__ __launch_bounds__(256, 1) void k_tower32(TowerArgs A) {
 #pragma unroll
                 for (int r = 0; r < 16; r++) hv[ct][pt][r] += Bv.v[ct][r >> 2][r & 3];
         LnStat L;
-        ln_reduce<2>(hv, L, HEAD, wave, lane, s_stat, ln_parity SC_STAMP_PASS(-2));
+        ln_reduce<2>(hv, L, HEAD, wave, lane, s_stat, ln_parity, bad SC_STAMP_PASS(-2));
         ch_load_lds<2>(G, HP_V + HEAD * 4, wave, h);
         ch_load_lds<2>(E, HP_V + 2 * HEAD * 4, wave, h);
         ln_apply<2>(hv, L, G, E, true);
@@ -635,7 +640,7 @@ __global__ __launch_bounds__(256, 1) void k_tower32(TowerArgs A) {
         ring_fill<1, 4, 4>(hr2, net.wb + net.o_pconv2, wave, lane);
         __builtin_amdgcn_sched_barrier(0);
         LnStat L;
-        ln_reduce<2>(hp, L, HEAD, wave, lane, s_stat, ln_parity SC_STAMP_PASS(-2));
+        ln_reduce<2>(hp, L, HEAD, wave, lane, s_stat, ln_parity, bad SC_STAMP_PASS(-2));
         ch_load_lds<2>(G, HP_P1 + HEAD * 4, wave, h);
         ch_load_lds<2>(E, HP_P1 + 2 * HEAD * 4, wave, h);
         ln_apply<2>(hp, L, G, E, false);
@@ -652,7 +657,7 @@ __global__ __launch_bounds__(256, 1) void k_tower32(TowerArgs A) {
         conv_mma32<HEAD, 1, 1, 4, HP, 4, 1, true>(XA_BYTES, net.wb + net.o_pconv2, wave, lane, pxh, z, hr2, 0);
         // padded channels (>=73) have zero weights, bias, gamma, beta: they add 0 to both LN sums
         LnStat L;
-        ln_reduce<1>(z, L, 73, wave, lane, s_stat, ln_parity SC_STAMP_PASS(-2));
+        ln_reduce<1>(z, L, 73, wave, lane, s_stat, ln_parity, bad SC_STAMP_PASS(-2));
         ch_load_lds<1>(G, HP_P2 + POL_PAD * 4, wave, h);
         ch_load_lds<1>(E, HP_P2 + 2 * POL_PAD * 4, wave, h);
         ln_apply<1>(z, L, G, E, false);
@@ -664,6 +669,10 @@ __global__ __launch_bounds__(256, 1) void k_tower32(TowerArgs A) {
                 const int ch = chan32<1>(wave, 0, r >> 2, h) + (r & 3);
                 if (ch < 73) s_z[ch * 64 + bp[pt]] = z[0][pt][r];  // Flatten is channel-major (module.py:75)
             }
+        if (bad) {   // see LnStat: make the NaN visible in the priors and (through the value features) in the value
+            s_z[lane] = __builtin_nanf("");
+            A.hval[(size_t)pos * 64 * HEAD + tid] = 0x7fc0;
+        }
     }
     __syncthreads();
     // ---- log_softmax over 4672 (module.py:80), then the legal-move gather of torch.rs:148-175
