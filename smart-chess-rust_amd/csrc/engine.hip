@@ -40,7 +40,7 @@ struct sc_engine {
     scnn::NetDev net{};
     uint16_t* d_wb = nullptr;
     float* d_wf = nullptr;
-    int ksplit = 32;
+    int ksplit = getenv("SC_KSPLIT") ? atoi(getenv("SC_KSPLIT")) : 64;   // split-K of value_head.ffn.0 (16, 32 or 64)
     // scratch, grown on demand
     int cap = 0;
     int8_t* d_boards = nullptr;
@@ -440,7 +440,6 @@ int sc_selfplay_create(sc_engine* e, int device_id, const sc_selfplay_config* cf
         }
     }
     if (e && cfg->evaluator == SC_EVAL_NET) {
-        if (e->ksplit > 32) return fail("ksplit > 32 unsupported by the fused value tail");
         rc |= sp_alloc(sp, &sp->d_hval, G * 64 * 256);
         rc |= sp_alloc(sp, &sp->d_vpart, (size_t)e->ksplit * G * 128);
         if (rc) {

@@ -564,12 +564,15 @@ __device__ inline float value_from_partials(const SpParams& p, int g, int lane) 
 #pragma unroll
     for (int h = 0; h < 2; h++) {
         int j = lane + 64 * h;
-        float acc[32];
-#pragma unroll
-        for (int ks = 0; ks < 32; ks++) acc[ks] = ks < p.vf_ksplit ? p.vpart[((size_t)ks * p.n_slots + g) * 128 + j] : 0.f;
         float s = wf[p.vf_fc1b + j];
+        // fixed-order sum of the split-K partials, fetched 32 at a time (all loads in flight before the first add)
+        for (int k0 = 0; k0 < p.vf_ksplit; k0 += 32) {
+            float acc[32];
 #pragma unroll
-        for (int ks = 0; ks < 32; ks++) s += acc[ks];
+            for (int ks = 0; ks < 32; ks++) acc[ks] = k0 + ks < p.vf_ksplit ? p.vpart[((size_t)(k0 + ks) * p.n_slots + g) * 128 + j] : 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 32; ks++) s += acc[ks];
+        }
 #pragma unroll
         for (int k = 0; k < 7; k++) s += m[k] * wf[p.vf_fc1m + k * 128 + j];
         s = s > 0.f ? s : 0.f;

@@ -34,13 +34,14 @@ def main(tag, ch):
     src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
     dst = os.path.join(ROOT, "profiles")
     os.makedirs(dst, exist_ok=True)
-    st = glob.glob(os.path.join(src, f"stats_c{ch}", "*", "*kernel_stats.csv"))[0]
+    newest = lambda pat: max(glob.glob(pat), key=os.path.getmtime)   # a re-run leaves older files beside the new ones
+    st = newest(os.path.join(src, f"stats_c{ch}", "*", "*kernel_stats.csv"))
     shutil.copyfile(st, os.path.join(dst, f"{tag}_c{ch}_kernel_stats.csv"))
     b = os.path.join(src, f"bench_stats_c{ch}.json")
     if os.path.exists(b):
         shutil.copyfile(b, os.path.join(dst, f"{tag}_c{ch}_bench_under_rocprof.json"))
-    fetch = per_kernel(glob.glob(os.path.join(src, f"pmc_fetch_c{ch}", "*", "*counter_collection.csv"))[0], "FETCH_SIZE")
-    write = per_kernel(glob.glob(os.path.join(src, f"pmc_write_c{ch}", "*", "*counter_collection.csv"))[0], "WRITE_SIZE")
+    fetch = per_kernel(newest(os.path.join(src, f"pmc_fetch_c{ch}", "*", "*counter_collection.csv")), "FETCH_SIZE")
+    write = per_kernel(newest(os.path.join(src, f"pmc_write_c{ch}", "*", "*counter_collection.csv")), "WRITE_SIZE")
     rows = []
     traffic = {}
     tpath = os.path.join(dst, "traffic.json")
