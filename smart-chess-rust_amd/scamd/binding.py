@@ -225,7 +225,7 @@ class ChessHip:
         p = pri[0]
         if argmax:  # post_process_distr argmax branch (src/chess.rs:880-889)
             o = np.zeros_like(p)
-            o[int(np.argmax(p))] = 1.0
+            o[len(p) - 1 - int(np.argmax(p[::-1]))] = 1.0   # Iterator::max_by keeps the LAST maximum
             p = o
         return list(enc["legal_moves"][0]), p, float(val[0])
 
