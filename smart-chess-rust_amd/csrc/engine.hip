@@ -440,6 +440,7 @@ int sc_selfplay_create(sc_engine* e, int device_id, const sc_selfplay_config* cf
         }
     }
     if (e && cfg->evaluator == SC_EVAL_NET) {
+        if (e->ksplit != 32 && e->ksplit != 64) return fail("split-K of the value head must be 32 or 64");
         rc |= sp_alloc(sp, &sp->d_hval, G * 64 * 256);
         rc |= sp_alloc(sp, &sp->d_vpart, (size_t)e->ksplit * G * 128);
         if (rc) {

@@ -225,6 +225,9 @@ __device__ __forceinline__ void dev_select(const SpParams& p, int g, int lane, i
     SC_STAMP(2);
     GameCtl& c = p.ctl[g];
     const GameCtl cs = uniform(c);  // one 64-byte fetch instead of a chain of dependent field loads
+    // the root position and the root header ride in the same round trip (their addresses depend on g only)
+    const Position root = uniform(p.tpos[(size_t)g * p.tpos_cap]);
+    NodeHdr hdr = uniform(p.H[(size_t)g * p.node_cap]);
     if (cs.status != ST_ACTIVE) {
         if (lane == 0) c.leaf_kind = LK_NONE;
         return;
@@ -240,12 +243,10 @@ __device__ __forceinline__ void dev_select(const SpParams& p, int g, int lane, i
     const Position* hist = p.hist + (size_t)g * p.hist_cap;
     Position* tpos = p.tpos + (size_t)g * p.tpos_cap;
     const int root_ply = cs.ply;
-    const Position root = uniform(tpos[0]);
     const int root_turn = root.turn;
     const int dmax = p.max_depth < DEPTH_LDS ? p.max_depth : DEPTH_LDS;
 
     int node = 0, depth = 0, parent_ps = 0;
-    NodeHdr hdr = uniform(H[0]);
     if (lane == 0) {
         path[0] = 0;
         s_ps[0] = 0;
@@ -560,24 +561,50 @@ __device__ inline float value_from_partials(const SpParams& p, int g, int lane) 
         u = (u + 0x7fffu + ((u >> 16) & 1u)) & 0xffff0000u;
         m[k] = __builtin_bit_cast(float, u);
     }
-    float part = 0.f;
+    // lane owns output columns 2*lane, 2*lane+1; ALL split-K partials are requested before the first add (one L2
+    // round trip instead of one per 32 partials), then summed in fixed ascending order (same order and column
+    // mapping as k_value_finish: the two paths are bitwise identical)
+    const int j = 2 * lane;
+    float2 acc[64];
+    const float* vp = p.vpart + (size_t)g * 128 + j;
+    const size_t vstride = (size_t)p.n_slots * 128;
+    // split-K is 32 or 64 (engine.hip): two unconditional batches -- a per-partial bound check makes the compiler
+    // branch around (and wait for) every single load
 #pragma unroll
-    for (int h = 0; h < 2; h++) {
-        int j = lane + 64 * h;
-        float s = wf[p.vf_fc1b + j];
-        // fixed-order sum of the split-K partials, fetched 32 at a time (all loads in flight before the first add)
-        for (int k0 = 0; k0 < p.vf_ksplit; k0 += 32) {
-            float acc[32];
+    for (int ks = 0; ks < 32; ks++) acc[ks] = *reinterpret_cast<const float2*>(vp + (size_t)ks * vstride);
+    if (p.vf_ksplit > 32) {
 #pragma unroll
-            for (int ks = 0; ks < 32; ks++) acc[ks] = k0 + ks < p.vf_ksplit ? p.vpart[((size_t)(k0 + ks) * p.n_slots + g) * 128 + j] : 0.f;
+        for (int ks = 32; ks < 64; ks++) acc[ks] = *reinterpret_cast<const float2*>(vp + (size_t)ks * vstride);
+    } else {
 #pragma unroll
-            for (int ks = 0; ks < 32; ks++) s += acc[ks];
-        }
-#pragma unroll
-        for (int k = 0; k < 7; k++) s += m[k] * wf[p.vf_fc1m + k * 128 + j];
-        s = s > 0.f ? s : 0.f;
-        part += s * wf[p.vf_fc2w + j];
+        for (int ks = 32; ks < 64; ks++) acc[ks] = make_float2(0.f, 0.f);
     }
+    const float2 bias = *reinterpret_cast<const float2*>(wf + p.vf_fc1b + j);
+    const float2 w2 = *reinterpret_cast<const float2*>(wf + p.vf_fc2w + j);
+    float2 wm[7];
+#pragma unroll
+    for (int k = 0; k < 7; k++) wm[k] = *reinterpret_cast<const float2*>(wf + p.vf_fc1m + k * 128 + j);
+    float s0 = bias.x, s1 = bias.y;
+#pragma unroll
+    for (int ks = 0; ks < 32; ks++) {
+        s0 += acc[ks].x;
+        s1 += acc[ks].y;
+    }
+    if (p.vf_ksplit > 32) {
+#pragma unroll
+        for (int ks = 32; ks < 64; ks++) {
+            s0 += acc[ks].x;
+            s1 += acc[ks].y;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 7; k++) {
+        s0 += m[k] * wm[k].x;
+        s1 += m[k] * wm[k].y;
+    }
+    s0 = s0 > 0.f ? s0 : 0.f;
+    s1 = s1 > 0.f ? s1 : 0.f;
+    float part = s0 * w2.x + s1 * w2.y;
     part = wave_sum_f(part);
     float v = tanhf(part + wf[p.vf_fc2b]);
     return v * (float)(meta[0] * 2 - 1);
@@ -587,6 +614,16 @@ __device__ __forceinline__ void dev_expand(SpParams& p, int g, int lane, Positio
     Position& s_np = *s_np_p;
     GameCtl& c = p.ctl[g];
     const GameCtl cs = uniform(c);  // one 64-byte fetch instead of a chain of dependent field loads
+    // speculative fetches (addresses depend on g only), in flight together with the control block
+    const int pth = lane < p.max_depth ? p.path[(size_t)g * p.max_depth + lane] : 0;
+    float prv[4];
+    uint16_t lmv[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int i = lane + 64 * k;
+        prv[k] = i < MAXC ? p.prior[(size_t)g * MAXC + i] : 0.f;
+        lmv[k] = i < MAXC ? p.legal_mv[(size_t)g * MAXC + i] : (uint16_t)0;
+    }
     if (cs.status != ST_ACTIVE || cs.leaf_kind == LK_NONE) return;
     const size_t nb = (size_t)g * p.node_cap;
     int32_t* N = p.N + nb;
@@ -603,22 +640,34 @@ __device__ __forceinline__ void dev_expand(SpParams& p, int g, int lane, Positio
     float value = cs.leaf_value;
     int n_nodes = cs.n_nodes, n_exp = cs.n_exp;
     uint32_t err = 0;
+    // Everything whose address depends on the game only (the recorded path, the leaf's priors and legal moves) was
+    // requested together with the control block above; the statistics of the path nodes are requested now, before
+    // the value tail, so the whole expansion costs two L2 round trips instead of five dependent ones.
+    const bool inpath = lane < plen;
+    int n0 = 0;
+    float w0 = 0.f;
+    if (inpath) {
+        n0 = N[pth];
+        w0 = W[pth];
+    }
     if (kind == LK_EVAL) {
         value = p.vf_fused ? value_from_partials(p, g, lane) : p.value[g];
         int n = cs.n_legal;
         if (n_nodes + n > p.node_cap || n_exp + 1 >= p.tpos_cap) {
             err = ERR_POOL_OVERFLOW;
         } else {
-            const uint16_t* lm = p.legal_mv + (size_t)g * MAXC;
-            const float* pr = p.prior + (size_t)g * MAXC;
-            for (int i = lane; i < n; i += 64) {
-                int id = n_nodes + i;
-                N[id] = 0;
-                W[id] = 0.0f;
-                P[id] = pr[i];
-                U[id] = 0.0f;
-                MV[id] = lm[i];
-                H[id] = NodeHdr{-1, 0, 0};
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                int i = lane + 64 * k;
+                if (i < n) {
+                    int id = n_nodes + i;
+                    N[id] = 0;
+                    W[id] = 0.0f;
+                    P[id] = prv[k];
+                    U[id] = 0.0f;
+                    MV[id] = lmv[k];
+                    H[id] = NodeHdr{-1, 0, 0};
+                }
             }
             if (lane == 0) H[leaf] = NodeHdr{n_nodes, (uint16_t)n, (uint16_t)n_exp};
             n_nodes += n;
@@ -628,7 +677,11 @@ __device__ __forceinline__ void dev_expand(SpParams& p, int g, int lane, Positio
         if (lane == 0) H[leaf] = NodeHdr{value == 0.0f ? -2 : value > 0.0f ? -3 : -4, 0, 0};
     }
     // backward (mcts.rs:90-98): every node of the path, root included
-    for (int d = lane; d < plen; d += 64) {
+    if (inpath) {
+        N[pth] = n0 + 1;
+        W[pth] = w0 + value;
+    }
+    for (int d = lane + 64; d < plen; d += 64) {
         int nd = path[d];
         N[nd] += 1;
         W[nd] += value;

@@ -772,17 +772,26 @@ __global__ __launch_bounds__(64) void k_value_finish(VfinArgs A) {
     float m[7];
 #pragma unroll
     for (int k = 0; k < 7; k++) m[k] = bf2f(f2bf((float)A.meta[(size_t)pos * A.meta_stride + k]));  // meta is fed as bf16 (torch.rs:120-123)
-    float part = 0.f;
-#pragma unroll
-    for (int h = 0; h < 2; h++) {
-        int j = lane + 64 * h;
-        float s = wf[A.net.f_fc1b + j];
-        for (int ks = 0; ks < A.ksplit; ks++) s += A.vpart[((size_t)ks * A.n_pos + pos) * FC1_N + j];
-#pragma unroll
-        for (int k = 0; k < 7; k++) s += m[k] * wf[A.net.f_fc1m + k * FC1_N + j];
-        s = s > 0.f ? s : 0.f;
-        part += s * wf[A.net.f_fc2w + j];
+    // lane owns columns 2*lane, 2*lane+1; partials summed in ascending split order (same arithmetic as the fused
+    // tail in mcts_kernels.hpp value_from_partials)
+    const int j = 2 * lane;
+    const float2 bias = *reinterpret_cast<const float2*>(wf + A.net.f_fc1b + j);
+    float s0 = bias.x, s1 = bias.y;
+    for (int ks = 0; ks < A.ksplit; ks++) {
+        const float2 a = *reinterpret_cast<const float2*>(A.vpart + ((size_t)ks * A.n_pos + pos) * FC1_N + j);
+        s0 += a.x;
+        s1 += a.y;
     }
+#pragma unroll
+    for (int k = 0; k < 7; k++) {
+        const float2 w = *reinterpret_cast<const float2*>(wf + A.net.f_fc1m + k * FC1_N + j);
+        s0 = __fadd_rn(s0, __fmul_rn(m[k], w.x));   // no FMA contraction: the fused tail is built with -ffp-contract=off
+        s1 = __fadd_rn(s1, __fmul_rn(m[k], w.y));
+    }
+    s0 = s0 > 0.f ? s0 : 0.f;
+    s1 = s1 > 0.f ? s1 : 0.f;
+    const float2 w2 = *reinterpret_cast<const float2*>(wf + A.net.f_fc2w + j);
+    float part = __fadd_rn(__fmul_rn(s0, w2.x), __fmul_rn(s1, w2.y));
     for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
     if (lane == 0) {
         float v = tanhf(part + wf[A.net.f_fc2b]);
