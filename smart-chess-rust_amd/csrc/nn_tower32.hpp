@@ -27,7 +27,7 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 struct Stamp {
     bool on;
     long long prev;
-    long long t[16];
+    long long t[24];
     __device__ __forceinline__ void start() { if (on) prev = clock64(); }
     __device__ __forceinline__ void mark(int k) {
         if (on && k >= 0) {
@@ -380,7 +380,22 @@ __global__ __launch_bounds__(256, 1) void k_tower32(TowerArgs A) {
     f32x16 acc[CT][2];
     int ln_parity = 0;
     int bad = 0;   // a LayerNorm saw a NaN variance
+    // The fp32 residual stream: in registers for the narrow trunk (16 values per 32-channel tile and pixel tile; the
+    // conv loops leave room), parked in LDS for the wide one (LDS stores run at ~80 B/clk: 32 KB per block there).
+#ifdef SC_EXP_RES_LDS
+    constexpr bool RES_REG = false;
+#else
+    constexpr bool RES_REG = (C == 128);
+#endif
+    f32x16 res[RES_REG ? CT : 1][2];
     auto store_res = [&]() {
+        if constexpr (RES_REG) {
+#pragma unroll
+            for (int ct = 0; ct < CT; ct++)
+#pragma unroll
+                for (int pt = 0; pt < 2; pt++) res[ct][pt] = acc[ct][pt];
+            return;
+        }
 #pragma unroll
         for (int ct = 0; ct < CT; ct++)
 #pragma unroll
@@ -406,7 +421,7 @@ __global__ __launch_bounds__(256, 1) void k_tower32(TowerArgs A) {
     Stamp stampv;
     stampv.on = A.dbg && A.dbg_stage == 2000 && lane == 0;
     stampv.prev = 0;
-    for (int k = 0; k < 16; k++) stampv.t[k] = 0;
+    for (int k = 0; k < 24; k++) stampv.t[k] = 0;
     stampv.start();
 #endif
     bf16x8 ring[RS][CT];   // weight prefetch ring, carried from layer to layer
@@ -555,7 +570,11 @@ __global__ __launch_bounds__(256, 1) void k_tower32(TowerArgs A) {
                 const f32x4 sv = *reinterpret_cast<const f32x4*>(s_scl + ch);
 #pragma unroll
                 for (int pt = 0; pt < 2; pt++) {
-                    const f32x4 rv = *reinterpret_cast<const f32x4*>(Rs + (pt * 32 + i32) * RP + ch);
+                    f32x4 rv;
+                    if constexpr (RES_REG)
+                        rv = f32x4{res[ct][pt][4 * g], res[ct][pt][4 * g + 1], res[ct][pt][4 * g + 2], res[ct][pt][4 * g + 3]};
+                    else
+                        rv = *reinterpret_cast<const f32x4*>(Rs + (pt * 32 + i32) * RP + ch);
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
                         float y = acc[ct][pt][4 * g + k] * sv[k] + rv[k];
@@ -630,6 +649,7 @@ __global__ __launch_bounds__(256, 1) void k_tower32(TowerArgs A) {
                     *reinterpret_cast<uint2*>(A.hval + ((size_t)pos * 64 + bp[pt]) * HEAD + chan32<2>(wave, ct, g, h)) = v;
                 }
     }
+    SC_MARK(16);
     // ---- policy head (py/module.py:70-76): conv1x1 C->256, LN, conv1x1 256->73, LN (no ReLU between)
     {
         ChP<2> Bv, G, E;
@@ -648,6 +668,7 @@ __global__ __launch_bounds__(256, 1) void k_tower32(TowerArgs A) {
         store_image32<2>(hp, xb, wave, h);   // Xh aliases the residual area (dead after the trunk)
     }
     __syncthreads();
+    SC_MARK(17);
     {
         ChP<1> Bv, G, E;
         ch_load_lds<1>(Bv, HP_P2, wave, h);
@@ -675,6 +696,7 @@ __global__ __launch_bounds__(256, 1) void k_tower32(TowerArgs A) {
         }
     }
     __syncthreads();
+    SC_MARK(18);
     // ---- log_softmax over 4672 (module.py:80), then the legal-move gather of torch.rs:148-175
     float mx = -3.0e38f;
     for (int k = tid; k < 4672; k += 256) mx = fmaxf(mx, s_z[k]);
@@ -693,6 +715,7 @@ __global__ __launch_bounds__(256, 1) void k_tower32(TowerArgs A) {
         float* lp = A.logp + (size_t)pos * 4672;
         for (int k = tid; k < 4672; k += 256) lp[k] = s_z[k] - lse;
     }
+    SC_MARK(19);
     if (A.prior) {
         const int n = A.n_legal[pos];
         const uint16_t* li = A.legal_idx + (size_t)pos * 224;
@@ -709,7 +732,7 @@ __global__ __launch_bounds__(256, 1) void k_tower32(TowerArgs A) {
 #ifdef SC_EXP
     SC_MARK(15);
     if (stampv.on)
-        for (int k = 0; k < 16; k++) A.dbg[(size_t)pos * 64 * C + wave * 16 + k] = (float)stampv.t[k];
+        for (int k = 0; k < 24; k++) A.dbg[(size_t)pos * 64 * C + wave * 24 + k] = (float)stampv.t[k];
 #endif
 }
 

@@ -1,6 +1,7 @@
 #!/bin/bash
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $R
-timeout -k 10 200 python -m pytest tests -m gpu -x -q 2>&1 | tail -5
-timeout -k 10 200 python tools/dbg_cycles.py
+for i in 1 2 3; do
 timeout -k 10 120 python bench.py --cpu-budget 0 --steps 10 --no-alt
+SC_ENGINE_LIB=$R/smart-chess-rust_amd/lib_exp_reslds/libsc_engine.so timeout -k 10 120 python bench.py --cpu-budget 0 --steps 10 --no-alt
+done
