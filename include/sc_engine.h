@@ -89,6 +89,23 @@ int sc_encode_positions(sc_engine* engine_or_null, int device_id, int n, const u
                         int8_t* boards, int32_t* meta, uint16_t* legal_moves, uint16_t* legal_idx, int32_t* n_legal,
                         int32_t* outcome);
 
+/* Trace -> training tensors on the GPU: replaces libsmartchess.chess_encode_steps
+ * (reference src/lib.rs:46-128; consumer py/dataset.py:47-87) for a batch of recorded games.
+ *   moves / move_off     the played moves of game g: moves[move_off[g] .. move_off[g+1]); ply p (global index, game after
+ *                        game) is the position BEFORE moves[p]
+ *   child_mv / child_n / child_off   the searched children of ply p and their visit counts: [child_off[p], child_off[p+1])
+ *                        (a trace's steps[i][2] = [[uci, N, Q, uct], ...]; at most SC_MAX_MOVES per ply)
+ *   apply_mirror         the reference's colour-mirror augmentation (changes meta only; py/dataset.py negates the outcome)
+ * Outputs, host pointers, any of the first five may be NULL (P = move_off[n_games] plies):
+ *   boards int8[P][8][8][112], meta int32[P][7], dist float[P][4672] = N_i / (sum N + 1e-5) at the action index of
+ *   the real mover, legal_idx uint16[P][SC_MAX_MOVES] + n_legal int32[P] (the reference's `move_indices`),
+ *   status int32[n_games]: 0 ok; 1000+i: the children of ply i are not exactly the legal moves ("inconsistent moves",
+ *   the reference panics, lib.rs:64-76); -(i+1): the move played at ply i is not legal (lib.rs:78-80).  Outputs of a
+ *   game at and after its failing ply are unspecified. */
+int sc_encode_steps(sc_engine* engine_or_null, int device_id, int n_games, const uint16_t* moves, const uint32_t* move_off,
+                    const uint16_t* child_mv, const uint32_t* child_n, const uint32_t* child_off, int apply_mirror,
+                    int8_t* boards, int32_t* meta, float* dist, uint16_t* legal_idx, int32_t* n_legal, int32_t* status);
+
 /* ------------------------------------------------------------------ self-play (L-search) */
 enum { SC_EVAL_NET = 0, SC_EVAL_SYNTH = 1 }; /* SYNTH: integer-hash evaluator for exact search-parity tests */
 

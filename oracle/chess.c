@@ -750,3 +750,141 @@ void orc_encode(const orc_state* s, int8_t* boards, int32_t* meta) {
     meta[5] = (c->castling & oq) != 0;
     meta[6] = c->halfmove;
 }
+
+/* ------------------------------------------------------------------ training-tensor encoder
+ * libsmartchess.chess_encode_steps (reference src/lib.rs:46-128), restated LITERALLY: a `Board` snapshot per ply
+ * (FromPyObject src/chess.rs:355-412), optionally Board::rotate()d when apply_mirror (src/chess.rs:594-621),
+ * pushed to the FRONT of a LOOKBACK-deep deque (BoardHistory::push_front :813-818) and viewed with every stored
+ * board rotated once more when the pushed board's turn is Black (BoardHistory::view :827-842). */
+typedef struct {
+    int8_t pc[64];      /* piece_map: signed piece codes, square = rank*8+file of THIS board */
+    int turn;           /* 1 white */
+    int rep2, rep3;
+    int halfmove, fullmove;
+    int ks[2], qs[2];   /* has_{king,queen}side_castling_rights: (.0 = board.turn, .1 = !turn) at extraction */
+} tboard;
+
+static void tboard_from_state(const orc_state* s, tboard* b) {
+    const orc_pos* c = &s->cur;
+    memcpy(b->pc, c->board, 64);
+    b->turn = c->turn;
+    b->rep2 = is_repetition_at(s, s->n, 2);
+    b->rep3 = is_repetition_at(s, s->n, 3);
+    b->halfmove = c->halfmove;
+    b->fullmove = c->fullmove;
+    int t = c->turn;
+    uint8_t mk_ = t ? 1 : 4, mq = t ? 2 : 8, ok = t ? 4 : 1, oq = t ? 8 : 2;
+    b->ks[0] = (c->castling & mk_) != 0;
+    b->ks[1] = (c->castling & ok) != 0;
+    b->qs[0] = (c->castling & mq) != 0;
+    b->qs[1] = (c->castling & oq) != 0;
+}
+/* Board::rotate: squares rank -> 7-rank (Square::rotate :504-509), colours swapped, turn flipped, fullmove + 1 if
+ * White was to move, castling tuples swapped */
+static void tboard_rotate(const tboard* a, tboard* r) {
+    for (int sq = 0; sq < 64; sq++) r->pc[sq] = 0;
+    for (int sq = 0; sq < 64; sq++)
+        if (a->pc[sq]) r->pc[(7 - (sq >> 3)) * 8 + (sq & 7)] = (int8_t)-a->pc[sq];
+    r->turn = !a->turn;
+    r->rep2 = a->rep2;
+    r->rep3 = a->rep3;
+    r->halfmove = a->halfmove;
+    r->fullmove = a->fullmove + (a->turn == ORC_WHITE ? 1 : 0);
+    r->ks[0] = a->ks[1];
+    r->ks[1] = a->ks[0];
+    r->qs[0] = a->qs[1];
+    r->qs[1] = a->qs[0];
+}
+/* Board::encode_pieces :623-650 into the 14 planes at `base` of a [8][8][112] array */
+static void tboard_encode_pieces(const tboard* b, int8_t* full, int base) {
+    for (int sq = 0; sq < 64; sq++) {
+        int8_t* cell = full + sq * 112 + base;
+        for (int k = 0; k < 14; k++) cell[k] = 0;
+        int8_t pc = b->pc[sq];
+        if (pc) cell[(type_of(pc) - 1) + (pc > 0 ? 0 : 6)] = 1;
+        cell[12] = (int8_t)b->rep2;
+        cell[13] = (int8_t)b->rep3;
+    }
+}
+
+/* One game.  n_steps plies; next[i] = move played at ply i; child moves/counts of ply i at [coff[i], coff[i+1]).
+ * Outputs per ply: boards int8[7168], meta int32[7], dist float[4672], idx int32[224] (+ n_idx).
+ * Returns 0, or -(i+1) when ply i's next move is not legal, or 1000+i when its children are not exactly the legal
+ * moves (the reference panics: "inconsistent moves", lib.rs:64-76). */
+int orc_encode_steps(int n_steps, const orc_move* next, const orc_move* cmv, const uint32_t* ccnt, const uint32_t* coff,
+                     int apply_mirror, int8_t* boards, int32_t* meta, float* dist, int32_t* idx, int32_t* n_idx) {
+    orc_state* st = orc_state_new();
+    tboard hist[8];
+    int nh = 0;
+    int rc = 0;
+    for (int i = 0; i < n_steps; i++) {
+        orc_move legal[ORC_MAX_MOVES];
+        int nl = orc_legal_moves(st, legal);
+        int nc = (int)(coff[i + 1] - coff[i]);
+        const orc_move* cm = cmv + coff[i];
+        const uint32_t* cc = ccnt + coff[i];
+        /* sets must be equal (symmetric difference empty) */
+        int bad = 0;
+        for (int a = 0; a < nc && !bad; a++) {
+            int f = 0;
+            for (int b = 0; b < nl; b++) f |= legal[b] == cm[a];
+            if (!f) bad = 1;
+        }
+        for (int b = 0; b < nl && !bad; b++) {
+            int f = 0;
+            for (int a = 0; a < nc; a++) f |= legal[b] == cm[a];
+            if (!f) bad = 1;
+        }
+        if (bad) {
+            rc = 1000 + i;
+            break;
+        }
+        int has_next = 0;
+        for (int b = 0; b < nl; b++) has_next |= legal[b] == next[i];
+        if (!has_next) {
+            rc = -(i + 1);
+            break;
+        }
+        tboard tb, step;
+        tboard_from_state(st, &tb);
+        if (apply_mirror) tboard_rotate(&tb, &step);
+        else step = tb;
+        /* rotate_and_encode: by the ORIGINAL mover (lib.rs:85-92) */
+        int ori_turn = apply_mirror ? !step.turn : step.turn;
+        /* push_front */
+        if (nh == 8) nh = 7;
+        for (int k = nh; k > 0; k--) hist[k] = hist[k - 1];
+        hist[0] = step;
+        nh++;
+        int8_t* B = boards + (size_t)i * 7168;
+        memset(B, 0, 7168);
+        int rot = step.turn == ORC_BLACK;
+        for (int k = 0; k < nh; k++) {
+            tboard v;
+            if (rot) tboard_rotate(&hist[k], &v);
+            else v = hist[k];
+            tboard_encode_pieces(&v, B, 14 * k);
+        }
+        int32_t* M = meta + (size_t)i * 7;
+        M[0] = step.turn;
+        M[1] = step.fullmove;
+        M[2] = step.ks[0];
+        M[3] = step.qs[0];
+        M[4] = step.ks[1];
+        M[5] = step.qs[1];
+        M[6] = step.halfmove;
+        for (int b = 0; b < nl; b++) idx[(size_t)i * 224 + b] = orc_move_index(legal[b], ori_turn);
+        n_idx[i] = nl;
+        float* D = dist + (size_t)i * 4672;
+        for (int k = 0; k < 4672; k++) D[k] = 0.f;
+        uint32_t sum = 0;
+        for (int a = 0; a < nc; a++) sum += cc[a];
+        for (int a = 0; a < nc; a++) {
+            int ind = orc_move_index(cm[a], ori_turn);
+            D[ind] = (float)cc[a] / ((float)sum + 1e-5f);
+        }
+        orc_push(st, next[i]);
+    }
+    orc_state_free(st);
+    return rc;
+}

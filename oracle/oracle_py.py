@@ -93,6 +93,7 @@ def lib():
         "orc_move_from_uci": (u16, [C.c_char_p]),
         "orc_move_index": (i32, [u16, i32]),
         "orc_encode": (None, [vp, vp, vp]),
+        "orc_encode_steps": (i32, [i32, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp]),
         "orc_net_num_tensors": (i32, [i32]),
         "orc_net_tensor_shape": (C.c_int64, [i32, i32, i32, C.POINTER(i32), C.POINTER(i32)]),
         "orc_prng_weight": (C.c_float, [u64, i32, u64, C.c_double, C.c_double]),
@@ -217,6 +218,28 @@ class State:
 
     def pos_hash(self):
         return int(self.L.orc_pos_hash(self.h))
+
+
+def encode_steps(steps, apply_mirror=False):
+    """libsmartchess.chess_encode_steps (reference src/lib.rs:46-128): steps = [(next_move, [(move, count), ...]), ...]
+    with moves as uint16 or UCI strings -> (rc, boards int8[n,8,8,112], meta int32[n,7], dist f32[n,4672],
+    [move_indices per ply])"""
+    mv = lambda m: from_uci(m) if isinstance(m, str) else int(m)
+    n = len(steps)
+    nxt = np.array([mv(s[0]) for s in steps], np.uint16)
+    coff = np.zeros(n + 1, np.uint32)
+    for i, s in enumerate(steps):
+        coff[i + 1] = coff[i] + len(s[1])
+    cm = np.array([mv(c[0]) for s in steps for c in s[1]] or [0], np.uint16)
+    cc = np.array([int(c[1]) for s in steps for c in s[1]] or [0], np.uint32)
+    boards = np.zeros((max(n, 1), 8, 8, 112), np.int8)
+    meta = np.zeros((max(n, 1), 7), np.int32)
+    dist = np.zeros((max(n, 1), 4672), np.float32)
+    idx = np.zeros((max(n, 1), 224), np.int32)
+    nidx = np.zeros(max(n, 1), np.int32)
+    rc = lib().orc_encode_steps(n, _ptr(nxt), _ptr(cm), _ptr(cc), _ptr(coff), int(bool(apply_mirror)), _ptr(boards), _ptr(meta),
+                                _ptr(dist), _ptr(idx), _ptr(nidx))
+    return rc, boards[:n], meta[:n], dist[:n], [idx[i, :nidx[i]].copy() for i in range(n)]
 
 
 def move_index(m, turn):

@@ -84,6 +84,10 @@ orc_move orc_move_from_uci(const char*);
 int orc_move_index(orc_move m, int turn);            /* Move::encode after rotate-if-black */
 /* _encode(): boards int8[8][8][112], meta int32[7]; history limited to `n` plies back to root */
 void orc_encode(const orc_state*, int8_t* boards, int32_t* meta);
+/* libsmartchess.chess_encode_steps (src/lib.rs:46-128) for one game; see chess.c.  No reference fixture holds an
+ * output of this function: PARITY UNPINNED except for the hand-derived cases in tests/test_oracle_training.py. */
+int orc_encode_steps(int n_steps, const orc_move* next, const orc_move* cmv, const uint32_t* ccnt, const uint32_t* coff,
+                     int apply_mirror, int8_t* boards, int32_t* meta, float* dist, int32_t* idx, int32_t* n_idx);
 
 #ifdef __cplusplus
 }

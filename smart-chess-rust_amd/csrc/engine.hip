@@ -295,7 +295,7 @@ int sc_encode_positions(sc_engine* e, int device_id, int n, const uint16_t* move
     HIPOK(hipMemcpy(d_off, move_off, ((size_t)n + 1) * 4, hipMemcpyHostToDevice));
     HIPOK(hipMemset(d_lm, 0, (size_t)n * 224 * 2));
     HIPOK(hipMemset(d_li, 0, (size_t)n * 224 * 2));
-    scl::encode_positions(n, d_moves, d_off, d_hist, hist_cap, d_boards, d_meta, d_lm, d_li, d_nl, d_out, nullptr);
+    scl::encode_positions(n, d_moves, d_off, nullptr, d_hist, hist_cap, d_boards, d_meta, d_lm, d_li, d_nl, d_out, nullptr);
     HIPOK(hipGetLastError());
     HIPOK(hipDeviceSynchronize());
     if (boards) HIPOK(hipMemcpy(boards, d_boards, (size_t)n * 7168, hipMemcpyDeviceToHost));
@@ -306,6 +306,98 @@ int sc_encode_positions(sc_engine* e, int device_id, int n, const uint16_t* move
     if (outcome) HIPOK(hipMemcpy(outcome, d_out, (size_t)n * 16, hipMemcpyDeviceToHost));
     (void)hipFree(d_moves); hipFree(d_off); hipFree(d_hist); hipFree(d_boards); hipFree(d_meta); hipFree(d_nl); hipFree(d_out);
     (void)hipFree(d_lm); hipFree(d_li);
+    return 0;
+}
+
+// libsmartchess.chess_encode_steps (reference src/lib.rs:46-128) for a batch of recorded games; see include/sc_engine.h
+int sc_encode_steps(sc_engine* e, int device_id, int n_games, const uint16_t* moves, const uint32_t* move_off,
+                    const uint16_t* child_mv, const uint32_t* child_n, const uint32_t* child_off, int apply_mirror, int8_t* boards,
+                    int32_t* meta, float* dist, uint16_t* legal_idx, int32_t* n_legal, int32_t* status) {
+    if (n_games < 0 || !move_off || !child_off || !status) return fail("bad argument");
+    if (n_games == 0) return 0;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail("no HIP device available: libsc_engine has no CPU fallback", -3);
+    HIPOK(hipSetDevice(e ? e->device : device_id));
+    const uint32_t total = move_off[n_games];
+    uint32_t maxlen = 0;
+    for (int g = 0; g < n_games; g++) {
+        if (move_off[g + 1] < move_off[g]) return fail("move_off not monotonic");
+        maxlen = std::max(maxlen, move_off[g + 1] - move_off[g]);
+        status[g] = 0;
+    }
+    if (maxlen > 4000) return fail("move list too long");
+    for (uint32_t p = 0; p < total; p++)
+        if (child_off[p + 1] < child_off[p] || child_off[p + 1] - child_off[p] > 224) return fail("child_off: more than 224 children or not monotonic");
+    if (total == 0) return 0;
+    // one position per ply: (start of its game, number of moves already played)
+    std::vector<uint32_t> pstart(total), plen(total), pgame(total);
+    for (int g = 0; g < n_games; g++)
+        for (uint32_t t = move_off[g]; t < move_off[g + 1]; t++) {
+            pstart[t] = move_off[g];
+            plen[t] = t - move_off[g];
+            pgame[t] = (uint32_t)g;
+        }
+    const int hist_cap = (int)maxlen + 2;
+    const uint32_t CH = 8192;  // plies per launch (bounds the replay scratch: CH * hist_cap * 80 B)
+    const uint32_t nchild = child_off[total];
+    uint16_t *d_moves = nullptr, *d_cmv = nullptr, *d_lm = nullptr, *d_li = nullptr;
+    uint32_t *d_start = nullptr, *d_len = nullptr, *d_cn = nullptr, *d_coff = nullptr;
+    sc::Position* d_hist = nullptr;
+    int8_t* d_boards = nullptr;
+    int32_t *d_meta = nullptr, *d_nl = nullptr, *d_flags = nullptr, *d_out = nullptr;
+    float* d_dist = nullptr;
+    const uint32_t cap = std::min(CH, total);
+    HIPOK(dalloc(&d_moves, total));
+    HIPOK(dalloc(&d_cmv, (size_t)nchild + 1));
+    HIPOK(dalloc(&d_cn, (size_t)nchild + 1));
+    HIPOK(dalloc(&d_coff, (size_t)cap + 1));
+    HIPOK(dalloc(&d_start, cap));
+    HIPOK(dalloc(&d_len, cap));
+    HIPOK(dalloc(&d_hist, (size_t)cap * hist_cap));
+    HIPOK(dalloc(&d_boards, (size_t)cap * 7168));
+    HIPOK(dalloc(&d_meta, (size_t)cap * 7));
+    HIPOK(dalloc(&d_nl, cap));
+    HIPOK(dalloc(&d_flags, cap));
+    HIPOK(dalloc(&d_out, (size_t)cap * 4));
+    HIPOK(dalloc(&d_lm, (size_t)cap * 224));
+    HIPOK(dalloc(&d_li, (size_t)cap * 224));
+    HIPOK(dalloc(&d_dist, (size_t)cap * 4672));
+    HIPOK(hipMemcpy(d_moves, moves, (size_t)total * 2, hipMemcpyHostToDevice));
+    if (nchild) {
+        HIPOK(hipMemcpy(d_cmv, child_mv, (size_t)nchild * 2, hipMemcpyHostToDevice));
+        HIPOK(hipMemcpy(d_cn, child_n, (size_t)nchild * 4, hipMemcpyHostToDevice));
+    }
+    std::vector<int32_t> flags(cap), replay(4 * (size_t)cap);
+    std::vector<uint32_t> coff(cap + 1);
+    for (uint32_t p0 = 0; p0 < total; p0 += CH) {
+        const uint32_t n = std::min(CH, total - p0);
+        for (uint32_t i = 0; i <= n; i++) coff[i] = child_off[p0 + i];   // absolute offsets into d_cmv / d_cn
+        HIPOK(hipMemcpy(d_coff, coff.data(), ((size_t)n + 1) * 4, hipMemcpyHostToDevice));
+        HIPOK(hipMemcpy(d_start, pstart.data() + p0, (size_t)n * 4, hipMemcpyHostToDevice));
+        HIPOK(hipMemcpy(d_len, plen.data() + p0, (size_t)n * 4, hipMemcpyHostToDevice));
+        HIPOK(hipMemset(d_li, 0, (size_t)n * 224 * 2));
+        scl::encode_positions((int)n, d_moves, d_start, d_len, d_hist, hist_cap, d_boards, d_meta, d_lm, d_li, d_nl, d_out, nullptr);
+        // the ply's own move is moves[start + len] = d_moves + p0 + i
+        scl::steps_dist((int)n, d_lm, d_nl, d_moves + p0, d_cmv, d_cn, d_coff, apply_mirror, d_meta, d_dist, d_flags, nullptr);
+        HIPOK(hipGetLastError());
+        HIPOK(hipDeviceSynchronize());
+        if (boards) HIPOK(hipMemcpy(boards + (size_t)p0 * 7168, d_boards, (size_t)n * 7168, hipMemcpyDeviceToHost));
+        if (meta) HIPOK(hipMemcpy(meta + (size_t)p0 * 7, d_meta, (size_t)n * 28, hipMemcpyDeviceToHost));
+        if (dist) HIPOK(hipMemcpy(dist + (size_t)p0 * 4672, d_dist, (size_t)n * 4672 * 4, hipMemcpyDeviceToHost));
+        if (legal_idx) HIPOK(hipMemcpy(legal_idx + (size_t)p0 * 224, d_li, (size_t)n * 224 * 2, hipMemcpyDeviceToHost));
+        if (n_legal) HIPOK(hipMemcpy(n_legal + p0, d_nl, (size_t)n * 4, hipMemcpyDeviceToHost));
+        HIPOK(hipMemcpy(flags.data(), d_flags, (size_t)n * 4, hipMemcpyDeviceToHost));
+        // first failing ply of each game, with the reference's precedence (children first, then the played move)
+        for (uint32_t i = 0; i < n; i++) {
+            const uint32_t g = pgame[p0 + i];
+            if (status[g] != 0) continue;
+            const int ply = (int)plen[p0 + i];
+            if (flags[i] & 1) status[g] = 1000 + ply;
+            else if (flags[i] & 2) status[g] = -(ply + 1);
+        }
+    }
+    (void)hipFree(d_moves); hipFree(d_cmv); hipFree(d_cn); hipFree(d_coff); hipFree(d_start); hipFree(d_len); hipFree(d_hist);
+    (void)hipFree(d_boards); hipFree(d_meta); hipFree(d_nl); hipFree(d_flags); hipFree(d_out); hipFree(d_lm); hipFree(d_li); hipFree(d_dist);
     return 0;
 }
 

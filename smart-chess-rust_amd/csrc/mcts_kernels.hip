@@ -13,10 +13,17 @@ void synth_eval(const sc::SpParams& p, hipStream_t s) { hipLaunchKernelGGL(sc::k
 void set_position(const sc::SpParams& p, int slot, const uint16_t* d_moves, int n_moves, hipStream_t s) {
     hipLaunchKernelGGL(sc::k_set_position, dim3(1), dim3(64), 0, s, p, slot, d_moves, n_moves);
 }
-void encode_positions(int n_pos, const uint16_t* d_moves, const uint32_t* d_move_off, sc::Position* d_hist, int hist_cap,
-                      int8_t* boards, int32_t* meta, uint16_t* legal_mv, uint16_t* legal_idx, int32_t* n_legal,
+void encode_positions(int n_pos, const uint16_t* d_moves, const uint32_t* d_move_off, const uint32_t* d_move_len, sc::Position* d_hist,
+                      int hist_cap, int8_t* boards, int32_t* meta, uint16_t* legal_mv, uint16_t* legal_idx, int32_t* n_legal,
                       int32_t* outcome, hipStream_t s) {
-    hipLaunchKernelGGL(sc::k_encode_positions, dim3(n_pos), dim3(64), 0, s, n_pos, d_moves, d_move_off, d_hist, hist_cap,
+    hipLaunchKernelGGL(sc::k_encode_positions, dim3(n_pos), dim3(64), 0, s, n_pos, d_moves, d_move_off, d_move_len, d_hist, hist_cap,
                        boards, meta, legal_mv, legal_idx, n_legal, outcome);
+}
+void steps_dist(int n, const uint16_t* legal_mv, const int32_t* n_legal, const uint16_t* next_mv, const uint16_t* child_mv,
+                const uint32_t* child_n, const uint32_t* child_off, int apply_mirror, int32_t* meta, float* dist, int32_t* flags,
+                hipStream_t s) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(sc::k_steps_dist, dim3(n), dim3(64), 0, s, n, legal_mv, n_legal, next_mv, child_mv, child_n, child_off,
+                       apply_mirror, meta, dist, flags);
 }
 }  // namespace scl

@@ -883,8 +883,10 @@ __global__ __launch_bounds__(64) void k_set_position(SpParams p, int g, const ui
 // One wave per position: replay the move list from the start position (validating every move
 // against the legal-move generator), then produce the NN input, the legal moves + action indices
 // and outcome(claim_draw=True).  hist scratch: [n][hist_cap] Positions.
+// move_len (optional): position g replays moves[move_off[g] .. move_off[g] + move_len[g]) -- prefixes of one game
+// share their start (used by the training-tensor encoder: one position per ply).
 __global__ __launch_bounds__(64) void k_encode_positions(int n_pos, const uint16_t* moves, const uint32_t* move_off,
-                                                         Position* hist_all, int hist_cap, int8_t* boards, int32_t* meta,
+                                                         const uint32_t* move_len, Position* hist_all, int hist_cap, int8_t* boards, int32_t* meta,
                                                          uint16_t* legal_mv, uint16_t* legal_idx, int32_t* n_legal,
                                                          int32_t* outcome) {
     const int g = blockIdx.x, lane = threadIdx.x;
@@ -894,7 +896,7 @@ __global__ __launch_bounds__(64) void k_encode_positions(int n_pos, const uint16
     __shared__ Position s_np;
     Position* hist = hist_all + (size_t)g * hist_cap;
     const uint16_t* mv = moves + move_off[g];
-    int nm = (int)(move_off[g + 1] - move_off[g]);
+    int nm = move_len ? (int)move_len[g] : (int)(move_off[g + 1] - move_off[g]);
     Position cur;
     set_startpos(cur);
     cur.key = position_key(cur);
@@ -959,6 +961,72 @@ __global__ __launch_bounds__(64) void k_encode_positions(int n_pos, const uint16
             outcome[(size_t)g * 4 + 1] = winner;
             outcome[(size_t)g * 4 + 2] = in_check ? 1 : 0;
             outcome[(size_t)g * 4 + 3] = status;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ training tensors
+// Per ply of a recorded game: libsmartchess.chess_encode_steps (reference src/lib.rs:46-128) on top of
+// k_encode_positions (planes / meta / legal moves of the position BEFORE the ply's move):
+//   * checks the reference's two panics: the searched children must be exactly the legal moves, the played move
+//     must be legal -> flags[g] bit 0 / bit 1;
+//   * dist[index(move)] = count / (sum + 1e-5), index by the REAL mover (lib.rs:85-92, 105-113);
+//   * apply_mirror: the planes and dist do not change (the stored boards are rotated once at push and once more at
+//     view, lib.rs:80-98 + chess.rs:827-842 -- asserted on the oracle's literal restatement); meta becomes that of
+//     Board::rotate(): [!turn, fullmove + (turn==White), K(opp), Q(opp), K(mover), Q(mover), halfmove].
+// One wavefront per ply; HBM-bound writer (18.7 KB of dist per ply).
+__global__ __launch_bounds__(64) void k_steps_dist(int n, const uint16_t* legal_mv, const int32_t* n_legal, const uint16_t* next_mv,
+                                                   const uint16_t* child_mv, const uint32_t* child_n, const uint32_t* child_off,
+                                                   int apply_mirror, int32_t* meta, float* dist, int32_t* flags) {
+    const int g = blockIdx.x, lane = threadIdx.x;
+    if (g >= n) return;
+    __shared__ move_t s_lm[MAXC];
+    __shared__ int s_hit[MAXC];
+    const int nl = n_legal[g];
+    const uint32_t c0 = child_off[g];
+    const int nc = (int)(child_off[g + 1] - c0);
+    const int turn = meta[(size_t)g * 7];
+    float4* dz = reinterpret_cast<float4*>(dist + (size_t)g * 4672);
+    for (int i = lane; i < 4672 / 4; i += 64) dz[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = lane; i < MAXC; i += 64) {
+        s_lm[i] = i < nl ? legal_mv[(size_t)g * MAXC + i] : (move_t)0;
+        s_hit[i] = 0;
+    }
+    __syncthreads();
+    const move_t nx = next_mv[g];
+    int has_next = 0, bad = 0;
+    uint32_t sum = 0;
+    for (int i = lane; i < nl; i += 64) has_next |= (s_lm[i] == nx) ? 1 : 0;
+    for (int i = lane; i < nc; i += 64) {
+        const move_t m = child_mv[c0 + i];
+        int k = -1;
+        for (int j = 0; j < nl; j++)
+            if (s_lm[j] == m) k = j;
+        if (k < 0) bad = 1;
+        else s_hit[k] = 1;     // benign same-value race between duplicates
+        sum += child_n[c0 + i];
+    }
+    __syncthreads();
+    for (int i = lane; i < nl; i += 64) bad |= s_hit[i] ? 0 : 1;   // with nc == nl this also catches duplicate children
+    bad |= (nc != nl) ? 1 : 0;
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);   // u32 wrap-around, as the reference's u32 sum in release mode
+    const float den = (float)sum + 1e-5f;
+    for (int i = lane; i < nc; i += 64) {
+        const int idx = move_index(child_mv[c0 + i], turn);
+        if (idx >= 0) dist[(size_t)g * 4672 + idx] = (float)child_n[c0 + i] / den;
+    }
+    const bool any_bad = __ballot(bad) != 0, any_next = __ballot(has_next) != 0;
+    if (lane == 0) {
+        flags[g] = (any_bad ? 1 : 0) | (any_next ? 0 : 2);
+        if (apply_mirror) {
+            int32_t* m = meta + (size_t)g * 7;
+            const int32_t t = m[0], k0 = m[2], q0 = m[3], k1 = m[4], q1 = m[5];
+            m[0] = 1 - t;
+            m[1] = m[1] + (t == 1 ? 1 : 0);
+            m[2] = k1;
+            m[3] = q1;
+            m[4] = k0;
+            m[5] = q0;
         }
     }
 }

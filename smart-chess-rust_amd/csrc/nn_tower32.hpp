@@ -364,15 +364,15 @@ __global__ __launch_bounds__(256, 1) void k_tower32(TowerArgs A) {
     {
         const int p = tid >> 2, q = tid & 3;
         const uint32_t* src = reinterpret_cast<const uint32_t*>(A.boards + (size_t)pos * 7168 + p * 112 + q * 28);
-        bf16_t* dst = Xa + hidx(p) * CP + q * 28;
+        uint32_t* dst = reinterpret_cast<uint32_t*>(Xa + hidx(p) * CP + q * 28);   // 56-byte plane groups: 4-byte aligned
 #pragma unroll
         for (int k = 0; k < 7; k++) {
             uint32_t w = src[k];
+            float v[4];
 #pragma unroll
-            for (int b = 0; b < 4; b++) {
-                int8_t v = (int8_t)((w >> (8 * b)) & 0xff);
-                dst[k * 4 + b] = f2bf((float)v);
-            }
+            for (int b = 0; b < 4; b++) v[b] = (float)(int8_t)((w >> (8 * b)) & 0xff);
+            dst[2 * k] = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+            dst[2 * k + 1] = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
         }
     }
     __syncthreads();

@@ -8,10 +8,12 @@ reference's usage:
                                        ChessTS / ChessOnnx (src/backends/torch.rs:89-146)
   SelfPlay                       <->  bin `selfplay` (src/main.rs:155-238): same flag names
   encode_positions               <->  BoardState + _encode (src/chess.rs:665-877)
+  encode_steps                   <->  libsmartchess.chess_encode_steps (src/lib.rs:46-128), the trace -> training-tensor step
 
 There is NO CPU fallback: importing works anywhere (so the C ABI can be checked), but every
 compute entry point raises EngineError when the HIP library or a GPU is missing.
 """
-from .binding import (ChessHip, Engine, EngineError, SelfPlay, encode_positions, enqueue_interleaved, lib, lib_path,  # noqa: F401
+from .binding import (ChessHip, Engine, EngineError, SelfPlay, encode_positions, encode_steps, encode_steps_batch,  # noqa: F401
+                      enqueue_interleaved, lib, lib_path,
                       move_uci, uci_move, write_trace_json, TERMINATION)
 from . import binding  # noqa: F401

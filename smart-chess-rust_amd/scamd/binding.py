@@ -70,6 +70,7 @@ ABI = {
     "sc_selfplay_set_noise": (_i, [_vp, _i, _vp, _i]),
     "sc_selfplay_get_noise": (_i, [_vp, _i, _vp, _i]),
     "sc_selfplay_set_position": (_i, [_vp, _i, _vp, _i]),
+    "sc_encode_steps": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sc_trace_write_json": (_i, [C.c_char_p, C.POINTER(TraceInfo), _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sc_move_uci": (_i, [C.c_uint16, C.c_char_p]),
 }
@@ -199,6 +200,47 @@ def encode_positions(move_lists, device=0, engine=None):
     return dict(boards=boards, meta=meta, legal_moves=[lm[i, :nl[i]].copy() for i in range(n)],
                 legal_idx=[li[i, :nl[i]].copy() for i in range(n)], n_legal=nl, termination=oc[:, 0], winner=oc[:, 1],
                 is_check=oc[:, 2], status=oc[:, 3])
+
+
+def encode_steps_batch(games, apply_mirror=False, device=0, engine=None):
+    """Trace -> training tensors for a batch of games on the GPU (sc_encode_steps).
+    games: list of step lists [(next_move, [(move, count), ...]), ...] with moves as uint16 or UCI strings -- the
+    `steps` argument of libsmartchess.chess_encode_steps (reference src/lib.rs:46-50), one per game.
+    -> dict(boards int8[P,8,8,112], meta int32[P,7], dist f32[P,4672], move_indices [P lists], ply_off[n+1], status[n])"""
+    L = lib()
+    mv = lambda m: uci_move(m) if isinstance(m, str) else int(m)
+    n = len(games)
+    off = np.zeros(n + 1, np.uint32)
+    off[1:] = np.cumsum([len(g) for g in games])
+    P = int(off[n])
+    flat = np.asarray([mv(s[0]) for g in games for s in g] or [0], np.uint16)
+    coff = np.zeros(P + 1, np.uint32)
+    coff[1:] = np.cumsum([len(s[1]) for g in games for s in g])
+    cm = np.asarray([mv(c[0]) for g in games for s in g for c in s[1]] or [0], np.uint16)
+    cn = np.asarray([int(c[1]) for g in games for s in g for c in s[1]] or [0], np.uint32)
+    boards = np.zeros((max(P, 1), 8, 8, 112), np.int8)
+    meta = np.zeros((max(P, 1), 7), np.int32)
+    dist = np.zeros((max(P, 1), 4672), np.float32)
+    li = np.zeros((max(P, 1), MAX_MOVES), np.uint16)
+    nl = np.zeros(max(P, 1), np.int32)
+    status = np.zeros(max(n, 1), np.int32)
+    _check(L.sc_encode_steps(engine.h if engine else None, device, n, _p(flat), _p(off), _p(cm), _p(cn), _p(coff),
+                             int(bool(apply_mirror)), _p(boards), _p(meta), _p(dist), _p(li), _p(nl), _p(status)))
+    return dict(boards=boards[:P], meta=meta[:P], dist=dist[:P], move_indices=[li[i, :nl[i]].astype(np.int32) for i in range(P)],
+                ply_off=off, status=status[:n])
+
+
+def encode_steps(steps, apply_mirror=False, device=0, engine=None):
+    """Mirror of libsmartchess.chess_encode_steps(steps, apply_mirror) (reference src/lib.rs:46-128, used by
+    py/dataset.py:77): one game -> [(boards int8[8,8,112], meta int32[7], dist f32[4672], move_indices), ...].
+    Raises EngineError where the reference panics (children != legal moves, or an illegal played move)."""
+    r = encode_steps_batch([steps], apply_mirror, device, engine)
+    st = int(r["status"][0])
+    if st >= 1000:
+        raise EngineError(f"inconsistent moves at ply {st - 1000}")
+    if st < 0:
+        raise EngineError(f"num_act table doesn't include the next move (ply {-st - 1})")
+    return [(r["boards"][i], r["meta"][i], r["dist"][i], r["move_indices"][i]) for i in range(len(steps))]
 
 
 class ChessHip:

@@ -286,3 +286,86 @@ def test_selfplay_net_is_deterministic(scamd):
         sp.close()
     assert runs[0] == runs[1]
     eng.close()
+
+
+# ------------------------------------------------------------------ trace -> training tensors
+def _random_steps(orc, moves, rnd):
+    st = orc.State()
+    steps = []
+    for m in moves:
+        lm = st.legal_moves()
+        order = list(range(len(lm)))
+        rnd.shuffle(order)
+        steps.append((m, [(lm[i], rnd.randint(0, 200)) for i in order]))
+        st.push(m)
+    return steps
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mirror", [False, True])
+def test_encode_steps_bit_exact(scamd, orc, mirror):
+    """GPU training-tensor encoder == the oracle's literal restatement of libsmartchess.chess_encode_steps
+    (reference src/lib.rs:46-128): planes, meta, dist floats and move indices, bit for bit, on random games
+    (repetitions, promotions, castling, long games) with shuffled children."""
+    import random
+    rnd = random.Random(11)
+    games = [g for g, _ in random_games(orc, 40, 120, seed=77) if g]
+    games.append(games[0][:1])
+    steps = [_random_steps(orc, g, rnd) for g in games]
+    r = scamd.encode_steps_batch(steps, mirror)
+    assert (r["status"] == 0).all()
+    off = r["ply_off"]
+    for gi, st in enumerate(steps):
+        rc, b, m, d, idx = orc.encode_steps(st, mirror)
+        assert rc == 0
+        a, e = int(off[gi]), int(off[gi + 1])
+        assert (r["boards"][a:e] == b).all(), gi
+        assert (r["meta"][a:e] == m).all(), gi
+        assert (r["dist"][a:e].view(np.uint32) == d.view(np.uint32)).all(), gi
+        for k in range(e - a):
+            assert (r["move_indices"][a + k] == idx[k]).all(), (gi, k)
+    # the single-game mirror of the reference's Python API
+    one = scamd.encode_steps(steps[3], mirror)
+    rc, b, m, d, idx = orc.encode_steps(steps[3], mirror)
+    assert len(one) == len(steps[3]) and (one[5][0] == b[5]).all() and (one[5][2] == d[5]).all()
+
+
+@pytest.mark.gpu
+def test_encode_steps_errors_like_the_reference_panics(scamd, orc):
+    st = orc.State()
+    lm = st.legal_moves()
+    good = [(m, 1) for m in lm]
+    e2e4, e7e5 = orc.from_uci("e2e4"), orc.from_uci("e7e5")
+    st.push(e2e4)
+    good2 = [(m, 1) for m in st.legal_moves()]
+    cases = [[(e2e4, good[:-1])], [(e2e4, good + [(e7e5, 1)])], [(e7e5, good)], [(e2e4, good), (e2e4, good2)],
+             [(e2e4, good), (e7e5, good2[:-1] + [good2[0]])], [(e2e4, good), (e7e5, good2)]]
+    r = scamd.encode_steps_batch(cases)
+    assert r["status"].tolist() == [orc.encode_steps(c, False)[0] for c in cases] == [1000, 1000, -1, -2, 1001, 0]
+    with pytest.raises(scamd.EngineError):
+        scamd.encode_steps(cases[0])
+
+
+@pytest.mark.gpu
+def test_encode_steps_consumes_engine_traces(scamd, orc):
+    """end to end: games played by the GPU engine -> their traces -> training tensors; dist = N/(sum N + 1e-5) over
+    the recorded children, the chosen move carries the largest mass at temperature 0."""
+    eng = scamd.Engine(2, 128, seed=3)
+    sp = scamd.SelfPlay(eng, n_slots=8, n_games=8, rollout_num=24, num_steps=30, cpuct=2.5, temperature=0.0,
+                        temperature_switch=0, epsilon=0.15, seed=9)
+    sp.run()
+    traces = [sp.trace(g) for g in range(8)]
+    steps = [[(s[0], [(c[0], c[1]) for c in s[2]]) for s in t["steps"]] for t in traces]
+    r = scamd.encode_steps_batch(steps, engine=eng)
+    assert (r["status"] == 0).all()
+    p = 0
+    for t in traces:
+        for s in t["steps"]:
+            n = np.array([c[1] for c in s[2]], np.float32)
+            assert abs(float(r["dist"][p].sum()) - float(n.sum() / (n.sum() + 1e-5))) < 1e-5
+            best = int(np.argmax(r["dist"][p]))
+            turn = int(r["meta"][p][0])
+            assert r["dist"][p][best] == r["dist"][p][orc.move_index(s[0], turn)]
+            p += 1
+    sp.close()
+    eng.close()
