@@ -128,6 +128,8 @@ typedef struct {
                                    many games (>= 2*n_slots), older traces are overwritten (throughput runs) */
     int32_t own_stream;         /* 1: this handle launches on its own HIP stream, so several handles (groups of games)
                                    of one engine overlap on the GPU: one group's tree work hides under another's network */
+    int32_t tie_random;         /* temperature 0: 0 = first most-visited child (mcts::step, src/mcts.rs:298-306);
+                                   1 = uniformly random among the most visited (NNPlayer::bestmove, src/play.rs:268-277) */
 } sc_selfplay_config;
 
 int sc_selfplay_create(sc_engine* engine_or_null, int device_id, const sc_selfplay_config* cfg, sc_selfplay** out);
@@ -157,6 +159,12 @@ int sc_selfplay_get_stats(sc_selfplay*, sc_selfplay_stats* out);
  * timing(): ms_total = first enqueue -> last enqueue span; ms_nn = sum over the nn_launches sampled
  * tower launches (at most the last 4096). */
 int sc_selfplay_enable_timing(sc_selfplay*, int stride);
+/* Match play (the `play` binary's loop, src/play.rs:318-343; batched: every slot is one game of the same pairing).
+ * After this call the handle alternates players by ply: even plies are searched with `white`, odd plies with `black`
+ * (engines for SC_EVAL_NET; for SC_EVAL_SYNTH the two salts select two deterministic synthetic players).
+ * Needs n_games == n_slots (all games advance in lockstep, no slot recycling) and must precede the first enqueue.
+ * Reference settings: with_noise = 0, outcome_gate = -1 (outcome after every ply), num_steps = 200, tie_random = 1. */
+int sc_selfplay_set_players(sc_selfplay*, sc_engine* white, sc_engine* black, uint64_t synth_salt_white, uint64_t synth_salt_black);
 int sc_selfplay_timing(sc_selfplay*, int reset, float* ms_total, float* ms_nn, int64_t* nn_launches);
 
 /* Trace of a finished game = the reference's Trace<M,O> (src/trace.rs:5-9) in SoA form.

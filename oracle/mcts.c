@@ -46,9 +46,9 @@ uint64_t orc_pos_hash(const orc_state* s) {
 
 void orc_eval_synth(void* user, const orc_state* st, int n_legal, const orc_move* legal, const int* legal_idx,
                     float* priors, float* value) {
-    (void)user;
     (void)legal_idx;
-    uint64_t h = orc_pos_hash(st);
+    /* user: NULL, or a uint64 salt that makes a second, different deterministic "player" (match tests) */
+    uint64_t h = orc_pos_hash(st) ^ (user ? *(const uint64_t*)user : 0);
     uint64_t sum = 0;
     uint32_t w[ORC_MAX_MOVES];
     for (int i = 0; i < n_legal; i++) {
@@ -373,6 +373,84 @@ orc_trace* orc_selfplay_game(const orc_selfplay_cfg* cfg, orc_eval_fn eval, void
             tr->has_outcome = orc_outcome(st, &tr->termination, &tr->winner);
             if (tr->has_outcome) break;
         }
+    }
+    orc_state_free(st);
+    return tr;
+}
+/* ------------------------------------------------------------------ match play (src/play.rs:241-343)
+ * Two players share one tree cursor and alternate by ply (play_loop :318-343): White's evaluator searches on even
+ * plies, Black's on odd ones; Dirichlet noise off (:250); temperature 1 while the root depth is below the switch
+ * (:262-266); at temperature 0 a UNIFORMLY RANDOM child among those with the maximal visit count (:268-277; the
+ * build-defined draw is floor(u01 * count) with the same uniform as the temperature sampling); the chosen child is
+ * reset (step :300-301); outcome(claim_draw=True) is consulted after EVERY ply (:335), at most num_steps plies. */
+orc_trace* orc_match_game(const orc_selfplay_cfg* cfg, orc_eval_fn eval_w, void* user_w, orc_eval_fn eval_b, void* user_b) {
+    orc_trace* tr = (orc_trace*)calloc(1, sizeof *tr);
+    int cap = 4096, used = 0;
+    tr->child_move = (orc_move*)malloc(sizeof(orc_move) * (size_t)cap);
+    tr->child_n = (int32_t*)malloc(sizeof(int32_t) * (size_t)cap);
+    tr->child_q = (float*)malloc(sizeof(float) * (size_t)cap);
+    tr->child_uct = (float*)malloc(sizeof(float) * (size_t)cap);
+    orc_state* st = orc_state_new();
+    for (int i = 0; i < cfg->num_steps && i < ORC_MAX_PLY - 1; i++) {
+        orc_eval_fn eval = (i % 2 == 0) ? eval_w : eval_b;
+        void* user = (i % 2 == 0) ? user_w : user_b;
+        float temperature = i < cfg->temperature_switch ? 1.0f : cfg->temperature;
+        orc_search* s = orc_search_new(st, i);
+        for (int r = 0; r < cfg->rollout_num; r++) orc_search_sim(s, eval, user, cfg->cpuct, 0.15f, 0, NULL, cfg->faithful);
+        tr->n_sims += cfg->rollout_num;
+        tr->n_evals += s->n_evals;
+        node_t* root = &s->nodes[0];
+        int nc = root->n_child;
+        if (nc == 0) { /* bestmove -> None: the reference unwraps and panics (:329); a finished game never gets here */
+            orc_search_free(s);
+            break;
+        }
+        int32_t nact[ORC_MAX_MOVES];
+        for (int c = 0; c < nc; c++) nact[c] = s->nodes[root->first_child + c].n;
+        float u = (float)(orc_rng(cfg->seed, cfg->game_id, (uint64_t)i, 1, 0) >> 40) / 16777216.0f;
+        int choice;
+        if (temperature == 0.0f) {
+            int32_t mx = nact[0];
+            int cnt = 0;
+            for (int c = 1; c < nc; c++)
+                if (nact[c] > mx) mx = nact[c];
+            for (int c = 0; c < nc; c++) cnt += nact[c] == mx;
+            int k = (int)(u * (float)cnt);
+            if (k >= cnt) k = cnt - 1;
+            choice = 0;
+            for (int c = 0; c < nc; c++)
+                if (nact[c] == mx && k-- == 0) {
+                    choice = c;
+                    break;
+                }
+        } else {
+            choice = orc_choose_child(nact, nc, temperature, u);
+        }
+        if (used + nc > cap) {
+            cap = (used + nc) * 2;
+            tr->child_move = (orc_move*)realloc(tr->child_move, sizeof(orc_move) * (size_t)cap);
+            tr->child_n = (int32_t*)realloc(tr->child_n, sizeof(int32_t) * (size_t)cap);
+            tr->child_q = (float*)realloc(tr->child_q, sizeof(float) * (size_t)cap);
+            tr->child_uct = (float*)realloc(tr->child_uct, sizeof(float) * (size_t)cap);
+        }
+        for (int c = 0; c < nc; c++) {
+            node_t* ch = &s->nodes[root->first_child + c];
+            tr->child_move[used + c] = ch->move;
+            tr->child_n[used + c] = ch->n;
+            tr->child_q[used + c] = ch->q;
+            tr->child_uct[used + c] = ch->uct;
+        }
+        orc_move mv = s->nodes[root->first_child + choice].move;
+        tr->moves[tr->n_steps] = mv;
+        tr->q_root[tr->n_steps] = root->q;
+        tr->child_off[tr->n_steps] = used;
+        used += nc;
+        tr->n_steps++;
+        tr->child_off[tr->n_steps] = used;
+        orc_push(st, mv);
+        orc_search_free(s);
+        tr->has_outcome = orc_outcome(st, &tr->termination, &tr->winner);
+        if (tr->has_outcome) break;
     }
     orc_state_free(st);
     return tr;

@@ -115,6 +115,7 @@ def lib():
         "orc_search_set_rng": (None, [vp, u64]),
         "orc_choose_child": (i32, [vp, i32, C.c_float, C.c_float]),
         "orc_selfplay_game": (C.POINTER(Trace), [C.POINTER(SelfplayCfg), vp, vp]),
+        "orc_match_game": (C.POINTER(Trace), [vp, vp, vp, vp, vp]),
         "orc_trace_free": (None, [C.POINTER(Trace)]),
     }
     for name, (res, args) in sig.items():
@@ -351,3 +352,37 @@ def selfplay_game(evaluator="orc_eval_synth", user=None, rollout_num=20, num_ste
     res = {"steps": steps, "outcome": outcome, "n_sims": int(t.n_sims), "n_evals": int(t.n_evals)}
     L.orc_trace_free(tp)
     return res
+
+
+def _trace_to_dict(L, tp):
+    t = tp.contents
+    steps = []
+    for i in range(t.n_steps):
+        ch = [(uci(t.child_move[j]), int(t.child_n[j]), float(t.child_q[j]), float(t.child_uct[j]))
+              for j in range(t.child_off[i], t.child_off[i + 1])]
+        steps.append((uci(t.moves[i]), float(t.q_root[i]), ch))
+    outcome = None
+    if t.has_outcome:
+        outcome = {"termination": TERMINATION[t.termination], "winner": {1: "White", 0: "Black", -1: None}[t.winner]}
+    res = {"steps": steps, "outcome": outcome, "n_sims": int(t.n_sims), "n_evals": int(t.n_evals)}
+    L.orc_trace_free(tp)
+    return res
+
+
+def match_game(white="orc_eval_synth", user_white=None, black="orc_eval_synth", user_black=None, rollout_num=20, num_steps=200,
+               cpuct=1.5, temperature=0.0, temperature_switch=0, faithful=False, seed=0, game_id=0):
+    """src/play.rs:241-343 with two evaluators; user_* for the synthetic evaluator = an int salt (or None)"""
+    L = lib()
+    cfg = SelfplayCfg(rollout_num, num_steps, cpuct, temperature, temperature_switch, 0.15, 0, int(faithful), seed, game_id, -1)
+    keep = []
+
+    def prep(ev, user):
+        fn = ev if not isinstance(ev, str) else eval_fn(ev)
+        if isinstance(user, int):
+            box = C.c_uint64(user)
+            keep.append(box)
+            user = C.cast(C.byref(box), C.c_void_p)
+        return fn, user
+    fw, uw = prep(white, user_white)
+    fb, ub = prep(black, user_black)
+    return _trace_to_dict(L, L.orc_match_game(C.byref(cfg), fw, uw, fb, ub))

@@ -71,6 +71,9 @@ typedef struct {
 
 /* src/main.rs:155-238 */
 orc_trace* orc_selfplay_game(const orc_selfplay_cfg*, orc_eval_fn eval, void* user);
+/* src/play.rs:241-343 (two players, shared cursor, no noise, random tie-break, outcome after every ply); with_noise,
+ * epsilon and outcome_gate of the cfg are ignored */
+orc_trace* orc_match_game(const orc_selfplay_cfg*, orc_eval_fn eval_white, void* user_white, orc_eval_fn eval_black, void* user_black);
 void orc_trace_free(orc_trace*);
 
 #ifdef __cplusplus

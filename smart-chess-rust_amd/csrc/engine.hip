@@ -424,15 +424,31 @@ struct sc_selfplay {
     bool have_span = false;
     int64_t nn_launches = 0;
     bool pending_final = false;
+    // match play (sc_selfplay_set_players): player of even / odd plies
+    bool match = false;
+    sc_engine* player[2] = {nullptr, nullptr};
+    uint64_t salt[2] = {0, 0};
     scnn::bf16_t* d_hval = nullptr;  // value-head features of the current leaves [n_slots][64][256]
     float* d_vpart = nullptr;        // split-K partials of value_head.ffn.0 [ksplit][n_slots][128]
 };
 
 // complete the last enqueued simulation (expand / backward / ply transition) so that host reads see a
 // fully backed-up state; a following enqueue would have done the same work in its first launch
+// match play: the value tail of simulation step t uses the weights of the player that evaluated step t
+static void match_tail_params(const sc_selfplay* sp, sc::SpParams& q, int64_t t) {
+    if (!sp->match || sp->p.evaluator != SC_EVAL_NET || t < 0) return;
+    const sc_engine* ep = sp->player[(t / sp->p.rollout) & 1];
+    q.vf_w = ep->d_wf;
+    q.vf_fc1b = (uint32_t)ep->net.f_fc1b;
+    q.vf_fc1m = (uint32_t)ep->net.f_fc1m;
+    q.vf_fc2w = (uint32_t)ep->net.f_fc2w;
+    q.vf_fc2b = (uint32_t)ep->net.f_fc2b;
+}
 static void sp_flush(sc_selfplay* sp) {
     if (sp->pending_final) {
-        scl::mcts(sp->p, 1, 0, sp->stream);
+        sc::SpParams q = sp->p;
+        match_tail_params(sp, q, sp->sim_steps_enqueued - 1);
+        scl::mcts(q, 1, 0, sp->stream);
         sp->pending_final = false;
     }
 }
@@ -478,6 +494,8 @@ int sc_selfplay_create(sc_engine* e, int device_id, const sc_selfplay_config* cf
     p.outcome_gate = cfg->outcome_gate;
     p.evaluator = cfg->evaluator;
     p.external_noise = cfg->external_noise;
+    p.tie_random = cfg->tie_random;
+    p.synth_salt = 0;
     p.cpuct = cfg->cpuct;
     p.temperature = cfg->temperature;
     p.epsilon = cfg->epsilon;
@@ -593,12 +611,23 @@ int sc_selfplay_enqueue_sims(sc_selfplay* sp, int n) {
         sp->have_span = true;
     }
     for (int i = 0; i < n; i++) {
+        sc_engine* e = sp->engine;
+        sc::SpParams q = p;
+        if (sp->match) {
+            // All games are at the same ply: simulation step t belongs to ply t / rollout.  The search kernel first
+            // finishes step t-1 (value tail: the weights of THAT step's player), then selects the leaf that this
+            // step's player evaluates.
+            const int64_t t = sp->sim_steps_enqueued + i;
+            const int cur = (int)((t / p.rollout) & 1);
+            e = sp->player[cur];
+            q.synth_salt = sp->salt[cur];
+            match_tail_params(sp, q, t - 1);
+        }
         // finish the previous simulation (expand/backward/ply transition) and select + encode the next leaf
-        scl::mcts(p, 1, 1, s);
+        scl::mcts(q, 1, 1, s);
         if (p.evaluator == SC_EVAL_SYNTH) {
-            scl::synth_eval(p, s);
+            scl::synth_eval(q, s);
         } else {
-            sc_engine* e = sp->engine;
             bool timed = sp->timing_stride > 0 && (sp->nn_launches % sp->timing_stride) == 0;
             int slot = 0;
             if (timed) {
@@ -639,6 +668,26 @@ int sc_selfplay_enqueue_sims(sc_selfplay* sp, int n) {
     sp->sim_steps_enqueued += n;
     if (sp->timing_stride > 0) HIPOK(hipEventRecord(sp->ev_end, s));
     HIPOK(hipGetLastError());
+    return 0;
+}
+
+int sc_selfplay_set_players(sc_selfplay* sp, sc_engine* white, sc_engine* black, uint64_t salt_white, uint64_t salt_black) {
+    if (!sp) return fail("null handle");
+    if (sp->sim_steps_enqueued != 0) return fail("set_players must precede the first enqueue");
+    if (sp->cfg.n_games != sp->cfg.n_slots) return fail("match play needs n_games == n_slots (lockstep plies, no slot recycling)");
+    if (sp->cfg.evaluator == SC_EVAL_NET) {
+        if (!white || !black) return fail("match play with SC_EVAL_NET needs two engines");
+        if (white->device != sp->device || black->device != sp->device) return fail("both engines must live on the handle's device");
+        if (white->ksplit != sp->engine->ksplit || black->ksplit != sp->engine->ksplit) return fail("engines differ in split-K");
+        int rc = engine_reserve(white, sp->cfg.n_slots);
+        if (!rc) rc = engine_reserve(black, sp->cfg.n_slots);
+        if (rc) return rc;
+    }
+    sp->match = true;
+    sp->player[0] = white;
+    sp->player[1] = black;
+    sp->salt[0] = salt_white;
+    sp->salt[1] = salt_black;
     return 0;
 }
 

@@ -459,7 +459,7 @@ __global__ __launch_bounds__(64) void k_synth_eval(SpParams p) {
     GameCtl& c = p.ctl[g];
     if (c.status != ST_ACTIVE || c.leaf_kind != LK_EVAL) return;
     const Position& pos = p.tpos[(size_t)g * p.tpos_cap + c.n_exp];
-    uint64_t h = synth_pos_hash(pos);
+    uint64_t h = synth_pos_hash(pos) ^ p.synth_salt;
     int n = c.n_legal;
     const uint16_t* lm = p.legal_mv + (size_t)g * MAXC;
     unsigned long long sum = 0;
@@ -744,6 +744,19 @@ __device__ __forceinline__ void dev_expand(SpParams& p, int g, int lane, Positio
             }
         }
         choice = bi;
+        if (p.tie_random) {
+            // NNPlayer::bestmove (play.rs:268-277): uniform among the maxima; k = floor(u * count), in index order
+            int cnt = 0;
+            for (int i = 0; i < nc; i++) cnt += N[fc + i] == bn;
+            float u = (float)(sc_rng(p.seed, cs.game_id, (uint64_t)ply, 1, 0) >> 40) / 16777216.0f;
+            int k = (int)(u * (float)cnt);
+            if (k >= cnt) k = cnt - 1;
+            for (int i = 0; i < nc; i++)
+                if (N[fc + i] == bn && k-- == 0) {
+                    choice = i;
+                    break;
+                }
+        }
     } else {
         // WeightedIndex over N^(1/temp): sequential f32 cumulative sums, x = u*total,
         // index = number of cumulative weights (last excluded) <= x

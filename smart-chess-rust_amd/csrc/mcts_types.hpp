@@ -43,6 +43,8 @@ struct Counters {
 
 struct SpParams {
     int n_slots, rollout, num_steps, temp_switch, with_noise, outcome_gate, evaluator, external_noise;
+    int tie_random;        // temperature 0: uniformly random child among the most visited (match play, src/play.rs:268-277)
+    uint64_t synth_salt;   // synthetic evaluator: second deterministic "player" (match tests)
     float cpuct, temperature, epsilon;
     uint64_t seed, first_game_id;
     int node_cap, max_depth, hist_cap, tpos_cap, trace_cap, total_games;

@@ -27,7 +27,8 @@ class SelfplayConfig(C.Structure):
                 ("cpuct", C.c_float), ("temperature", C.c_float), ("temperature_switch", C.c_int32),
                 ("epsilon", C.c_float), ("with_noise", C.c_int32), ("outcome_gate", C.c_int32),
                 ("evaluator", C.c_int32), ("external_noise", C.c_int32), ("seed", C.c_uint64),
-                ("first_game_id", C.c_uint64), ("trace_capacity", C.c_int32), ("own_stream", C.c_int32)]
+                ("first_game_id", C.c_uint64), ("trace_capacity", C.c_int32), ("own_stream", C.c_int32),
+                ("tie_random", C.c_int32)]
 
 
 class Stats(C.Structure):
@@ -61,6 +62,7 @@ ABI = {
     "sc_selfplay_enqueue_interleaved": (_i, [_vp, _i, _i]),
     "sc_selfplay_run": (_i, [_vp, _i64]),
     "sc_selfplay_get_stats": (_i, [_vp, C.POINTER(Stats)]),
+    "sc_selfplay_set_players": (_i, [_vp, _vp, _vp, C.c_uint64, C.c_uint64]),
     "sc_selfplay_enable_timing": (_i, [_vp, _i]),
     "sc_selfplay_timing": (_i, [_vp, _i, C.POINTER(_f), C.POINTER(_f), C.POINTER(_i64)]),
     "sc_selfplay_get_trace": (_i, [_vp, _i, C.POINTER(TraceInfo), _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -243,6 +245,52 @@ def encode_steps(steps, apply_mirror=False, device=0, engine=None):
     return [(r["boards"][i], r["meta"][i], r["dist"][i], r["move_indices"][i]) for i in range(len(steps))]
 
 
+def elo(total, wins, losses):
+    """scripts/elo.py:15-21: Elo difference from Total/Win/Lost"""
+    import math
+    s = (wins + (total - wins - losses) / 2) / total
+    if s <= 0.0 or s >= 1.0:
+        return math.copysign(math.inf, s - 0.5)
+    return 400 * math.log(s / (1 - s), 10)
+
+
+def play_match(a, b, n_games=100, rollout=100, cpuct=1.5, temperature=0.0, temperature_switch=0, num_steps=200, seed=0,
+               swap=True):
+    """Batched `scripts/leader-board:44-54`: n_games with engine `a` as White and `b` as Black, then (swap) the same
+    number with the colours exchanged; every game is `play`'s loop (src/play.rs:241-343: no noise, outcome after every
+    ply, at most 200 plies, random tie-break).  -> dict(results per colour assignment, a's score, Elo of a over b)."""
+    out = {"as_white": None, "as_black": None}
+    tot = win = lost = 0
+    for key, (w, bl) in (("as_white", (a, b)), ("as_black", (b, a))):
+        if key == "as_black" and not swap:
+            break
+        sp = SelfPlay(w, n_slots=n_games, n_games=n_games, rollout_num=rollout, num_steps=num_steps, cpuct=cpuct,
+                      temperature=temperature, temperature_switch=temperature_switch, with_noise=False, outcome_gate=-1,
+                      seed=seed + (0 if key == "as_white" else 1), tie_random=True)
+        sp.set_players(w, bl)
+        sp.run()
+        res = {"White": 0, "Black": 0, "draw": 0, "unfinished": 0}
+        traces = []
+        for g in range(n_games):
+            t = sp.trace(g)
+            traces.append(t)
+            oc = t["outcome"] if t else None
+            if oc is None:
+                res["unfinished"] += 1
+            elif oc["winner"] is None:
+                res["draw"] += 1
+            else:
+                res[oc["winner"]] += 1
+        sp.close()
+        out[key] = dict(results=res, traces=traces)
+        a_col, b_col = ("White", "Black") if key == "as_white" else ("Black", "White")
+        tot += n_games
+        win += res[a_col]
+        lost += res[b_col]
+    out.update(total=tot, a_wins=win, b_wins=lost, elo_a_minus_b=elo(tot, win, lost))
+    return out
+
+
 class ChessHip:
     """Mirror of `impl Game<BoardState> for ChessTS` (src/backends/torch.rs:34-53) over the GPU engine.
 
@@ -282,12 +330,14 @@ class SelfPlay:
 
     def __init__(self, engine=None, n_slots=256, n_games=None, rollout_num=180, num_steps=150, cpuct=2.5,
                  temperature=0.0, temperature_switch=4, epsilon=0.15, with_noise=True, outcome_gate=100,
-                 evaluator="net", external_noise=False, seed=0, first_game_id=0, trace_capacity=0, own_stream=False, device=0):
+                 evaluator="net", external_noise=False, seed=0, first_game_id=0, trace_capacity=0, own_stream=False, device=0,
+                 tie_random=False):
         self.L = lib()
         self.engine = engine
         cfg = SelfplayConfig(n_slots, n_games if n_games is not None else n_slots, rollout_num, num_steps, cpuct,
                              temperature, temperature_switch, epsilon, int(with_noise), outcome_gate,
-                             0 if evaluator == "net" else 1, int(external_noise), seed, first_game_id, trace_capacity, int(own_stream))
+                             0 if evaluator == "net" else 1, int(external_noise), seed, first_game_id, trace_capacity, int(own_stream),
+                             int(tie_random))
         self.cfg = cfg
         h = C.c_void_p()
         _check(self.L.sc_selfplay_create(engine.h if engine else None, device, C.byref(cfg), C.byref(h)))
@@ -306,6 +356,11 @@ class SelfPlay:
 
     def enqueue(self, n_sims):
         _check(self.L.sc_selfplay_enqueue_sims(self.h, n_sims))
+
+    def set_players(self, white=None, black=None, salt_white=0, salt_black=0):
+        """match play (src/play.rs:318-343): even plies are searched by `white`, odd plies by `black`"""
+        self._players = (white, black)   # keep the engines alive
+        _check(self.L.sc_selfplay_set_players(self.h, white.h if white else None, black.h if black else None, salt_white, salt_black))
 
     def sync(self):
         _check(self.L.sc_selfplay_synchronize(self.h))

@@ -369,3 +369,61 @@ def test_encode_steps_consumes_engine_traces(scamd, orc):
             p += 1
     sp.close()
     eng.close()
+
+
+# ------------------------------------------------------------------ match play
+@pytest.mark.gpu
+def test_match_games_exact(scamd, orc):
+    """`play` loop (src/play.rs:241-343) batched on the GPU == the oracle's restatement, game for game: two different
+    deterministic synthetic players alternating by ply, no noise, random tie-break among the most visited children,
+    outcome after every ply."""
+    cfg = dict(rollout_num=16, num_steps=60, cpuct=1.5, temperature=0.0, temperature_switch=2)
+    sp = scamd.SelfPlay(None, n_slots=12, n_games=12, evaluator="synth", seed=21, first_game_id=40, with_noise=False,
+                        outcome_gate=-1, tie_random=True, **cfg)
+    sp.set_players(None, None, salt_white=0x1111, salt_black=0x2222)
+    sp.run()
+    assert sp.stats()["error_flags"] == 0
+    ties = 0
+    for gi in range(12):
+        tr = sp.trace(gi)
+        ref = orc.match_game(user_white=0x1111, user_black=0x2222, seed=21, game_id=tr["game_id"], **cfg)
+        assert tr["steps"] == ref["steps"], gi
+        assert tr["outcome"] == ref["outcome"], gi
+        for s in tr["steps"]:
+            mx = max(c[1] for c in s[2])
+            ties += sum(c[1] == mx for c in s[2]) > 1
+    assert ties > 0   # the random tie-break was exercised
+    # colours exchanged: a different game
+    sp2 = scamd.SelfPlay(None, n_slots=2, n_games=2, evaluator="synth", seed=21, first_game_id=40, with_noise=False,
+                         outcome_gate=-1, tie_random=True, **cfg)
+    sp2.set_players(None, None, salt_white=0x2222, salt_black=0x1111)
+    sp2.run()
+    ref = orc.match_game(user_white=0x2222, user_black=0x1111, seed=21, game_id=40, **cfg)
+    assert sp2.trace(0)["steps"] == ref["steps"] != sp.trace(0)["steps"]
+    with pytest.raises(scamd.EngineError):   # lockstep plies need n_games == n_slots
+        scamd.SelfPlay(None, n_slots=2, n_games=4, evaluator="synth").set_players(None, None, 1, 2)
+
+
+@pytest.mark.gpu
+def test_match_between_two_networks(scamd, orc):
+    """two engines of different depth play each other in both colour assignments; every trace replays legally, the
+    tally and the Elo formula of scripts/elo.py add up, and a net against itself gives the self-consistent result"""
+    a, b = scamd.Engine(2, 128, seed=1), scamd.Engine(1, 128, seed=2)
+    r = scamd.play_match(a, b, n_games=6, rollout=12, num_steps=24, seed=3)
+    assert r["total"] == 12
+    for key in ("as_white", "as_black"):
+        res = r[key]["results"]
+        assert sum(res.values()) == 6
+        for t in r[key]["traces"]:
+            st = orc.State()
+            for s in t["steps"]:
+                legal = st.legal_uci()
+                assert s[0] in legal and sorted(c[0] for c in s[2]) == sorted(legal)
+                st.push(orc.from_uci(s[0]))
+    assert r["a_wins"] + r["b_wins"] <= 12
+    assert scamd.elo(100, 60, 30) == pytest.approx(400 * np.log10(0.65 / 0.35))
+    # determinism: the same pairing and seed reproduces the same games
+    r2 = scamd.play_match(a, b, n_games=6, rollout=12, num_steps=24, seed=3, swap=False)
+    assert [t["steps"] for t in r2["as_white"]["traces"]] == [t["steps"] for t in r["as_white"]["traces"]]
+    a.close()
+    b.close()

@@ -80,3 +80,26 @@ def test_selfplay_trace_semantics(orc):
     # terminal positions back up +-1: checkmate for White seen from White = +1
     g2 = orc.selfplay_game(rollout_num=30, num_steps=8, with_noise=False, seed=4)
     assert len(g2["steps"]) == 8 and g2["outcome"] is None
+
+
+def test_match_game_rules(orc):
+    """oracle restatement of the `play` loop (src/play.rs:241-343): players alternate by ply, outcome after every ply,
+    temperature-0 ties resolved among the most visited children only"""
+    cfg = dict(rollout_num=12, num_steps=40, cpuct=1.5, temperature=0.0, temperature_switch=0, seed=4, game_id=7)
+    t = orc.match_game(user_white=1, user_black=2, **cfg)
+    assert t == orc.match_game(user_white=1, user_black=2, **cfg)
+    assert t["steps"] != orc.match_game(user_white=2, user_black=1, **cfg)["steps"]
+    st = orc.State()
+    for i, s in enumerate(t["steps"]):
+        assert sorted(c[0] for c in s[2]) == sorted(st.legal_uci())
+        mx = max(c[1] for c in s[2])
+        assert dict((c[0], c[1]) for c in s[2])[s[0]] == mx          # a most-visited child was played
+        assert sum(c[1] for c in s[2]) == cfg["rollout_num"] - 1     # fresh tree every ply (step() resets the child)
+        st.push(orc.from_uci(s[0]))
+        assert (st.outcome() is not None) == (t["outcome"] is not None and i == len(t["steps"]) - 1)
+    # identical players and no tie => the same game as noise-free self-play consulted every ply
+    same = orc.match_game(user_white=None, user_black=None, **cfg)
+    sp = orc.selfplay_game(rollout_num=12, num_steps=40, cpuct=1.5, temperature=0.0, temperature_switch=0, with_noise=False,
+                           seed=4, game_id=7, outcome_gate=-1)
+    k = next((i for i, s in enumerate(same["steps"]) if sum(c[1] == max(x[1] for x in s[2]) for c in s[2]) > 1), len(same["steps"]))
+    assert same["steps"][:k] == sp["steps"][:k]
