@@ -194,6 +194,9 @@ int sc_selfplay_set_noise(sc_selfplay*, int slot, const float* noise, int n);
 int sc_selfplay_get_noise(sc_selfplay*, int slot, float* noise, int cap);
 /* start slot from a given move list instead of the initial position (sc_search / chess_play_new, src/lib.rs:161-232) */
 int sc_selfplay_set_position(sc_selfplay*, int slot, const uint16_t* moves, int n_moves);
+/* per-call search options of chess_play_mcts(state, rollout, cpuct, noise) (src/lib.rs:233-247): applies to the
+ * simulations enqueued after the call */
+int sc_selfplay_set_search(sc_selfplay*, float cpuct, float epsilon, int with_noise);
 
 /* utility: trace-file JSON writer on caller-provided arrays (no GPU needed) */
 int sc_trace_write_json(const char* path, const sc_trace_info* info, const uint16_t* step_move, const float* step_q,

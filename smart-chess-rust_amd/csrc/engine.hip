@@ -928,6 +928,16 @@ int sc_selfplay_set_position(sc_selfplay* sp, int slot, const uint16_t* moves, i
     return 0;
 }
 
+int sc_selfplay_set_search(sc_selfplay* sp, float cpuct, float epsilon, int with_noise) {
+    if (!sp) return fail("null handle");
+    if (!(cpuct >= 0.f) || !(epsilon >= 0.f && epsilon <= 1.f)) return fail("bad search parameters");
+    // kernel parameters travel by value with every launch: the change applies to the launches enqueued after it
+    sp->p.cpuct = cpuct;
+    sp->p.epsilon = epsilon;
+    sp->p.with_noise = with_noise ? 1 : 0;
+    return 0;
+}
+
 int sc_move_uci(uint16_t move, char* buf8) { return sctrace::move_uci(move, buf8); }
 
 /* developer aid (not in the public header): cycle stamps of the last k_mcts launch, out[n_slots][8] */

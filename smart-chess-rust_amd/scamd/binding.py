@@ -62,6 +62,7 @@ ABI = {
     "sc_selfplay_enqueue_interleaved": (_i, [_vp, _i, _i]),
     "sc_selfplay_run": (_i, [_vp, _i64]),
     "sc_selfplay_get_stats": (_i, [_vp, C.POINTER(Stats)]),
+    "sc_selfplay_set_search": (_i, [_vp, _f, _f, _i]),
     "sc_selfplay_set_players": (_i, [_vp, _vp, _vp, C.c_uint64, C.c_uint64]),
     "sc_selfplay_enable_timing": (_i, [_vp, _i]),
     "sc_selfplay_timing": (_i, [_vp, _i, C.POINTER(_f), C.POINTER(_f), C.POINTER(_i64)]),
@@ -243,6 +244,98 @@ def encode_steps(steps, apply_mirror=False, device=0, engine=None):
     if st < 0:
         raise EngineError(f"num_act table doesn't include the next move (ply {-st - 1})")
     return [(r["boards"][i], r["meta"][i], r["dist"][i], r["move_indices"][i]) for i in range(len(steps))]
+
+
+class Play:
+    """Interactive engine handle: the `chess_play_*` functions of the reference's Python extension
+    (src/lib.rs:161-358: new / mcts / step / apply_move / inspect / dump_search_tree / inference / encode) on one
+    search slot of the GPU engine.  Differences: moves are UCI strings; `inspect()` returns the move list instead of a
+    python-chess board object; the tree keeps only the current subtree (the reference also keeps the never revisited
+    siblings of played moves), so `dump_search_tree()` shows the played line as a chain of single children."""
+
+    def __init__(self, engine, initial_moves=(), evaluator="net", seed=0):
+        self.engine = engine
+        self.moves = [m if isinstance(m, str) else move_uci(m) for m in initial_moves]
+        self._seed = seed
+        # rollout_num is the per-ply budget of the self-play driver: huge here, plies advance only through step()
+        self.sp = SelfPlay(engine, n_slots=1, n_games=1, rollout_num=60000, num_steps=4000, with_noise=False, outcome_gate=1 << 30,
+                           evaluator=evaluator, seed=seed)
+        self._rng = np.random.default_rng(seed)
+        self._set()
+
+    def _set(self):
+        mv = np.asarray([uci_move(m) for m in self.moves] or [0], np.uint16)
+        _check(self.sp.L.sc_selfplay_set_position(self.sp.h, 0, _p(mv), len(self.moves)))
+
+    def close(self):
+        self.sp.close()
+
+    def mcts(self, rollout, cpuct=2.5, noise=False):
+        """chess_play_mcts: `rollout` more simulations on the current tree (epsilon 0.15 as lib.rs:243)"""
+        _check(self.sp.L.sc_selfplay_set_search(self.sp.h, cpuct, 0.15, int(bool(noise))))
+        self.sp.enqueue(rollout)
+        self.sp.sync()
+
+    def _root_children(self):
+        t = self.sp.tree(0)
+        if t["n"].size == 0 or t["n_child"][0] == 0:
+            return t, 0, 0
+        return t, int(t["first_child"][0]), int(t["n_child"][0])
+
+    def step(self, temp=0.0):
+        """chess_play_step = mcts::step (src/mcts.rs:292-328): temperature 0 -> first most-visited child, else a
+        sample ~ N^(1/temp); descends and starts a fresh tree there.  Returns the move or None (no children)."""
+        t, fc, nc = self._root_children()
+        if nc == 0:
+            return None
+        n = t["n"][fc:fc + nc].astype(np.float32)
+        if temp == 0.0:
+            choice = int(np.argmax(n))
+        else:
+            w = n ** np.float32(1.0 / temp)
+            choice = int(self._rng.choice(nc, p=(w / w.sum()).astype(np.float64)))
+        mv = move_uci(t["move"][fc + choice])
+        self.apply_move(mv)
+        return mv
+
+    def apply_move(self, mov):
+        """chess_play_apply_move: play `mov` and continue from a fresh node"""
+        self.moves.append(mov if isinstance(mov, str) else move_uci(mov))
+        self._set()
+
+    def inspect(self):
+        """chess_play_inspect -> (None, move stack newest first, q_value of the current node, [(move, N, Q), ...])"""
+        t, fc, nc = self._root_children()
+        q = float(t["q"][0]) if t["q"].size else 0.0
+        ch = [(move_uci(t["move"][fc + i]), int(t["n"][fc + i]), float(t["q"][fc + i])) for i in range(nc)]
+        return None, list(reversed(self.moves)), q, ch
+
+    def dump_search_tree(self):
+        """chess_play_dump_search_tree: nested dicts with serde's field names (src/mcts.rs:43-56: step, depth, q,
+        num_act, children); step = [uci or None, colour of the side to move at the node]"""
+        t = self.sp.tree(0)
+        d0 = len(self.moves)
+
+        def node(i, depth, mv):
+            colour = "White" if depth % 2 == 0 else "Black"
+            fc, nc = int(t["first_child"][i]), int(t["n_child"][i])
+            kids = [node(fc + k, depth + 1, move_uci(t["move"][fc + k])) for k in range(nc)] if fc >= 0 else []
+            return {"step": [mv, colour], "depth": depth, "q": float(t["q"][i]), "num_act": int(t["n"][i]), "children": kids}
+        cur = node(0, d0, self.moves[-1] if self.moves else None) if t["n"].size else None
+        for d in range(d0 - 1, -1, -1):   # the played line above the current node
+            cur = {"step": [self.moves[d - 1] if d > 0 else None, "White" if d % 2 == 0 else "Black"], "depth": d, "q": 0.0,
+                   "num_act": 0, "children": [cur]}
+        return cur
+
+    def inference(self):
+        """chess_play_inference -> (legal moves, priors, value) of the current position (Game::predict)"""
+        steps, pri, val = ChessHip(self.engine).predict(self.moves)
+        return [move_uci(m) for m in steps], pri, val
+
+    def encode(self):
+        """chess_play_encode -> (boards int8[8,8,112], meta int32[7])"""
+        e = encode_positions([self.moves], engine=self.engine)
+        return e["boards"][0], e["meta"][0]
 
 
 def elo(total, wins, losses):

@@ -427,3 +427,60 @@ def test_match_between_two_networks(scamd, orc):
     assert [t["steps"] for t in r2["as_white"]["traces"]] == [t["steps"] for t in r["as_white"]["traces"]]
     a.close()
     b.close()
+
+
+# ------------------------------------------------------------------ interactive handle
+@pytest.mark.gpu
+def test_interactive_play_handle(scamd, orc):
+    """chess_play_* surface (src/lib.rs:161-358): searches accumulate on the current node, cpuct is a per-call option,
+    step()/apply_move() descend to a fresh node; trees equal the oracle's search"""
+    line = ["e2e4", "c7c5"]
+    pl = scamd.Play(None, initial_moves=line, evaluator="synth")
+    st = orc.State()
+    for m in line:
+        st.push(m)
+    srch = orc.Search(st, depth=2)
+    pl.mcts(10, cpuct=2.5)
+    pl.mcts(15, cpuct=1.25)                       # accumulates on the same tree (chess_play_mcts twice)
+    for _ in range(10):
+        srch.sim(cpuct=2.5, with_noise=False)
+    for _ in range(15):
+        srch.sim(cpuct=1.25, with_noise=False)
+    assert _same_tree(pl.sp.tree(0), srch.dump())
+    _, stack, q, ch = pl.inspect()
+    d = srch.dump()
+    assert stack == ["c7c5", "e2e4"] and q == float(d["q"][0])
+    assert [(c[1], c[2]) for c in ch] == [(int(d["n"][1 + i]), float(d["q"][1 + i])) for i in range(len(ch))]
+    assert [c[0] for c in ch] == st.legal_uci()
+    tree = pl.dump_search_tree()
+    assert tree["step"] == [None, "White"] and tree["children"][0]["step"] == ["e2e4", "Black"]
+    cur = tree["children"][0]["children"][0]
+    assert cur["depth"] == 2 and cur["num_act"] == 25 and len(cur["children"]) == len(ch)
+    mv = pl.step(0.0)                             # mcts::step, temperature 0: first most-visited child
+    best = max(c[1] for c in ch)
+    assert mv == next(c[0] for c in ch if c[1] == best)
+    assert pl.inspect()[3] == [] and pl.moves == line + [mv]
+    pl.apply_move(orc.State.legal_uci(_pushed(orc, pl.moves))[0])
+    pl.mcts(5)
+    assert pl.sp.tree(0)["n"][0] == 5 and len(pl.moves) == 4
+    pl.close()
+    # with a network: inference() and encode() are Game::predict and _encode of the current position
+    eng = scamd.Engine(1, 128, seed=2)
+    pn = scamd.Play(eng, initial_moves=["d2d4"])
+    steps, pri, val = pn.inference()
+    st2 = _pushed(orc, ["d2d4"])
+    assert steps == st2.legal_uci() and 0.9 < float(pri.sum()) <= 1.0 and -1.0 <= val <= 1.0   # (sum + 1e-5) renormalisation
+    b, m = pn.encode()
+    ob, om = st2.encode()
+    assert (b == ob).all() and (m == om).all()
+    pn.mcts(8, cpuct=2.0, noise=True)
+    assert sum(c[1] for c in pn.inspect()[3]) == 7
+    pn.close()
+    eng.close()
+
+
+def _pushed(orc, moves):
+    st = orc.State()
+    for m in moves:
+        st.push(m)
+    return st
