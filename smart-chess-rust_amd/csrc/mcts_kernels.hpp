@@ -21,6 +21,7 @@
 #include <hip/hip_runtime.h>
 
 #include "chess_history.hpp"
+#include "chess_rules_wave.hpp"
 #include "mcts_types.hpp"
 
 namespace sc {
@@ -412,11 +413,10 @@ __device__ __forceinline__ void dev_select(const SpParams& p, int g, int lane, i
     stage_history(ch, root_ply + depth, lane, s_hist);
     // scratch slot for the expansion (claimed in dev_expand if the leaf is not terminal)
     if (lane == 0) tpos[cs.n_exp] = pos;
-    MoveList ml{s_moves, 0};
-    bool in_check = gen_legal(pos, ml);
+    int n = 0;
+    bool in_check = gen_legal_wave(pos, s_moves, lane, n);   // lane = square (chess_rules_wave.hpp)
     __syncthreads();
     SC_STAMP(5);
-    int n = ml.n;
     if (n == 0) {
         if (lane == 0) {
             c.leaf_kind = LK_TERM_NEW;
@@ -918,11 +918,11 @@ __global__ __launch_bounds__(64) void k_encode_positions(int n_pos, const uint16
     int status = 0;
     int played = 0;
     for (int i = 0; i < nm && i + 1 < hist_cap; i++) {
-        MoveList ml{s_moves, 0};
-        gen_legal(cur, ml);
+        int nlm = 0;
+        gen_legal_wave(cur, s_moves, lane, nlm);
         __syncthreads();
         bool found = false;
-        for (int k = 0; k < ml.n; k++)
+        for (int k = 0; k < nlm; k++)
             if (s_moves[k] == mv[i]) found = true;
         __syncthreads();
         if (!found) {
@@ -942,10 +942,9 @@ __global__ __launch_bounds__(64) void k_encode_positions(int n_pos, const uint16
         played = i + 1;
     }
     HistChain hc{hist};
-    MoveList ml{s_moves, 0};
-    bool in_check = gen_legal(cur, ml);
+    int n = 0;
+    bool in_check = gen_legal_wave(cur, s_moves, lane, n);
     __syncthreads();
-    int n = ml.n;
     if (legal_mv)
         for (int i = lane; i < n; i += 64) legal_mv[(size_t)g * MAXC + i] = s_moves[i];
     if (legal_idx)
