@@ -27,9 +27,44 @@
 namespace sc {
 
 // ------------------------------------------------------------------ wave helpers (64 lanes)
-__device__ inline int wave_sum_i(int v) {
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+// Reductions inside the descent are latency chains (one per tree level): four DPP steps inside each row of 16 lanes
+// (quad_perm, row_half_mirror, row_mirror: plain VALU moves) and four readlanes to the scalar unit, instead of six
+// dependent trips through the LDS crossbar (ds_bpermute).
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int x) { return __builtin_amdgcn_update_dpp(0, x, CTRL, 0xf, 0xf, false); }
+__device__ __forceinline__ int wave_sum_i(int v) {
+    v += dpp_i<0xB1>(v);    // quad_perm [1,0,3,2]
+    v += dpp_i<0x4E>(v);    // quad_perm [2,3,0,1]
+    v += dpp_i<0x141>(v);   // row_half_mirror
+    v += dpp_i<0x140>(v);   // row_mirror
+    return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) +
+           __builtin_amdgcn_readlane(v, 48);
+}
+// index of the maximal u over the lanes with idx >= 0; ties go to the LARGER index (Iterator::max_by keeps the last
+// maximum, src/mcts.rs:78-88).  u must be finite.  Returns -1 when no lane has a candidate.  Wave-uniform result.
+__device__ __forceinline__ int wave_argmax_last(float u, int idx) {
+    // order-preserving map of a finite float to unsigned (+0.0 added first: -0.0 and +0.0 compare equal as floats)
+    unsigned b = __builtin_bit_cast(unsigned, u + 0.0f);
+    unsigned key = (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+    int hi = idx >= 0 ? (int)key : 0, lo = idx;   // compared as unsigned; lo = -1 marks "none" (never wins: hi = 0 ... see below)
+    auto step = [&](int ohi, int olo) {
+        const bool take = olo >= 0 && (lo < 0 || (unsigned)ohi > (unsigned)hi || ((unsigned)ohi == (unsigned)hi && olo > lo));
+        hi = take ? ohi : hi;
+        lo = take ? olo : lo;
+    };
+    step(dpp_i<0xB1>(hi), dpp_i<0xB1>(lo));
+    step(dpp_i<0x4E>(hi), dpp_i<0x4E>(lo));
+    step(dpp_i<0x141>(hi), dpp_i<0x141>(lo));
+    step(dpp_i<0x140>(hi), dpp_i<0x140>(lo));
+    int bh = __builtin_amdgcn_readlane(hi, 0), bl = __builtin_amdgcn_readlane(lo, 0);
+#pragma unroll
+    for (int r = 16; r < 64; r += 16) {
+        const int oh = __builtin_amdgcn_readlane(hi, r), ol = __builtin_amdgcn_readlane(lo, r);
+        const bool take = ol >= 0 && (bl < 0 || (unsigned)oh > (unsigned)bh || ((unsigned)oh == (unsigned)bh && ol > bl));
+        bh = take ? oh : bh;
+        bl = take ? ol : bl;
+    }
+    return bl;
 }
 __device__ inline float wave_sum_f(float v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -195,19 +230,24 @@ __device__ inline float u01_open(uint64_t& st) {
     st = mix64(st);
     return ((float)(st >> 40) + 0.5f) * (1.0f / 16777216.0f);
 }
+// Gamma(0.3, 1) sample for the Dirichlet(0.3) root noise (src/mcts.rs:123-130): Gamma(1.3) by Marsaglia-Tsang times
+// U^(1/0.3).  The draw happens for every child at EVERY simulation, on the critical path of the descent, so it uses
+// the hardware transcendentals (v_log / v_exp / v_cos / v_sqrt, ~1 ulp) instead of the correctly rounded library
+// routines (10x the instructions): the reference's noise comes from thread_rng, parity is distributional
+// (tests: test_root_noise_is_dirichlet).
 __device__ inline float gamma03(uint64_t st) {
     const float alpha = 0.3f;
-    float boost = powf(u01_open(st), 1.0f / alpha);
+    const float boost = __expf(__logf(u01_open(st)) * (1.0f / alpha));
     const float d = alpha + 1.0f - 1.0f / 3.0f;
-    const float c = 1.0f / sqrtf(9.0f * d);
+    const float c = 0.3390317518f;  // 1 / sqrt(9 d)
     for (int it = 0; it < 64; it++) {
         float a = u01_open(st), b = u01_open(st);
-        float x = sqrtf(-2.0f * logf(a)) * cosf(6.2831853f * b);
+        float x = __builtin_amdgcn_sqrtf(-2.0f * __logf(a)) * __builtin_amdgcn_cosf(b);   // v_cos_f32 takes revolutions
         float v = 1.0f + c * x;
         if (v <= 0.0f) continue;
         v = v * v * v;
         float u = u01_open(st);
-        if (logf(u) < 0.5f * x * x + d - d * v + d * logf(v)) return boost * d * v;
+        if (__logf(u) < 0.5f * x * x + d - d * v + d * __logf(v)) return boost * d * v;
     }
     return boost * d;
 }
@@ -335,15 +375,7 @@ __device__ __forceinline__ void dev_select(const SpParams& p, int g, int lane, i
                     }
                 }
             }
-            for (int o = 32; o > 0; o >>= 1) {
-                float ou = __shfl_xor(best_u, o, 64);
-                int oi = __shfl_xor(best_i, o, 64);
-                bool take = oi >= 0 && (best_i < 0 || ou > best_u || (ou == best_u && oi > best_i));
-                if (take) {
-                    best_u = ou;
-                    best_i = oi;
-                }
-            }
+            best_i = wave_argmax_last(best_u, best_i);
         }
         best_i = __builtin_amdgcn_readfirstlane(best_i);
         // header of the chosen child: owned by lane best_i & 63, register best_i >> 6
