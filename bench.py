@@ -101,11 +101,16 @@ def cpu_baseline(n_blocks, C, budget_s, rollout):
 def run_gpu(args, rank, world, local_rank):
     import scamd
 
-    G, R = args.games, args.rollout
+    R = args.rollout
     res = {}
-    for tag, C in (("main", args.channels),) + ((("alt", 256 if args.channels == 128 else 128),) if args.alt and world == 1 else ()):
+    # main = the BASELINE configuration; the optional extras (single GPU only, short) are reported under "also":
+    # the other trunk width, and twice the games in two interleaved groups (one group's search and value FC1 run under
+    # the other group's network launch -- what a 512-games-per-GPU deployment gets from the same kernels)
+    runs = [("main", args.channels, args.games, max(1, args.groups))]
+    if args.alt and world == 1:
+        runs += [("alt", 256 if args.channels == 128 else 128, args.games, max(1, args.groups)), ("x2", args.channels, 2 * args.games, 2)]
+    for tag, C, G, K in runs:
         eng = scamd.Engine(args.blocks, C, seed=1, device=local_rank)
-        K = max(1, args.groups)
         assert G % K == 0
         sps = [scamd.SelfPlay(eng, n_slots=G // K, n_games=10 ** 7 // K, trace_capacity=4 * G // K, rollout_num=R, num_steps=150,
                               cpuct=2.5, temperature=0.0, temperature_switch=4, epsilon=0.15, with_noise=True, seed=1234,
@@ -146,7 +151,7 @@ def run_gpu(args, rank, world, local_rank):
         res[tag] = dict(C=C, seconds=t1 - t0, steps=steps, sims=s1["sims_done"] - s0["sims_done"],
                         nn_evals=s1["nn_evals"] - s0["nn_evals"], err=s1["error_flags"],
                         tower_ms=sum(t["ms_tower_sum"] for t in tms) / max(nl, 1), tower_launches=nl,
-                        span_ms=max(t["ms_total"] for t in tms), groups=K)
+                        span_ms=max(t["ms_total"] for t in tms), groups=K, games=G)
         for sp in sps:
             sp.close()
         eng.close()
@@ -279,6 +284,12 @@ def main():
                                "tower_avg_ms": round(a["tower_ms"], 4),
                                "roofline_frac": round(args.games * fa / (a["tower_ms"] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4)
                                if a["tower_ms"] > 0 else None}
+            if "x2" in res:
+                x = res["x2"]
+                out["also_2x_games"] = {"games_per_gpu": x["games"], "groups": x["groups"], "net": f"{args.blocks}x{x['C']}",
+                                        "value": round(x["sims"] / x["seconds"], 1),
+                                        "ms_per_step": round(1e3 * x["seconds"] / x["steps"], 3),
+                                        "note": "two interleaved groups of games on two HIP streams; not the BASELINE configuration"}
             if world == 1 and args.cpu_budget > 0:
                 out["cpu_baseline"] = cpu_baseline(args.blocks, m["C"], args.cpu_budget, args.rollout)
         print(json.dumps(out), flush=True)

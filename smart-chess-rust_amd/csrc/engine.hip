@@ -537,6 +537,7 @@ int sc_selfplay_create(sc_engine* e, int device_id, const sc_selfplay_config* cf
     rc |= sp_alloc(sp, &p.t_cq, T * S * 224, false);
     rc |= sp_alloc(sp, &p.t_cu, T * S * 224, false);
     rc |= sp_alloc(sp, &p.cnt, 1);
+    rc |= sp_alloc(sp, &p.slot_cnt, (size_t)cfg->n_slots * 2);
     if (rc) {
         std::string keep = g_err;
         sc_selfplay_destroy(sp);
@@ -720,8 +721,15 @@ int sc_selfplay_get_stats(sc_selfplay* sp, sc_selfplay_stats* out) {
     HIPOK(hipMemcpy(ctl.data(), sp->p.ctl, ctl.size() * sizeof(sc::GameCtl), hipMemcpyDeviceToHost));
     int active = 0;
     for (auto& g : ctl) active += g.status == sc::ST_ACTIVE;
-    out->sims_done = (int64_t)c.sims_done;
-    out->nn_evals = (int64_t)c.nn_evals;
+    std::vector<unsigned long long> sc((size_t)sp->p.n_slots * 2);
+    HIPOK(hipMemcpy(sc.data(), sp->p.slot_cnt, sc.size() * 8, hipMemcpyDeviceToHost));
+    unsigned long long sims = 0, evals = 0;
+    for (int g = 0; g < sp->p.n_slots; g++) {
+        sims += sc[(size_t)g * 2];
+        evals += sc[(size_t)g * 2 + 1];
+    }
+    out->sims_done = (int64_t)sims;
+    out->nn_evals = (int64_t)evals;
     out->games_finished = c.games_finished;
     out->games_active = active;
     out->error_flags = c.err;

@@ -269,6 +269,13 @@ __device__ __forceinline__ void dev_select(const SpParams& p, int g, int lane, i
     // the root position and the root header ride in the same round trip (their addresses depend on g only)
     const Position root = uniform(p.tpos[(size_t)g * p.tpos_cap]);
     NodeHdr hdr = uniform(p.H[(size_t)g * p.node_cap]);
+    // ... and so do the root's children: the tree is rebuilt every ply with the root at node 0 and its children at
+    // nodes 1..nc (first expansion), so their statistics can be requested before the header is known
+    const size_t nb0 = (size_t)g * p.node_cap + 1 + lane;
+    const bool pf_ok = 1 + lane < p.node_cap;
+    const int pf_n = pf_ok ? p.N[nb0] : 0;
+    const float pf_w = pf_ok ? p.W[nb0] : 0.f, pf_p = pf_ok ? p.P[nb0] : 0.f;
+    const NodeHdr pf_h = pf_ok ? p.H[nb0] : NodeHdr{-1, 0, 0};
     if (cs.status != ST_ACTIVE) {
         if (lane == 0) c.leaf_kind = LK_NONE;
         return;
@@ -311,10 +318,17 @@ __device__ __forceinline__ void dev_select(const SpParams& p, int g, int lane, i
             if (r < nr) {
                 int i = lane + 64 * r;
                 bool ok = i < nc;
-                cn[r] = ok ? N[fc + i] : 0;
-                cw[r] = ok ? W[fc + i] : 0.f;
-                cp[r] = ok ? P[fc + i] : 0.f;
-                ch_[r] = ok ? H[fc + i] : NodeHdr{-1, 0, 0};
+                if (r == 0 && depth == 0 && fc == 1) {   // prefetched with the control block
+                    cn[0] = ok ? pf_n : 0;
+                    cw[0] = ok ? pf_w : 0.f;
+                    cp[0] = ok ? pf_p : 0.f;
+                    ch_[0] = ok ? pf_h : NodeHdr{-1, 0, 0};
+                } else {
+                    cn[r] = ok ? N[fc + i] : 0;
+                    cw[r] = ok ? W[fc + i] : 0.f;
+                    cp[r] = ok ? P[fc + i] : 0.f;
+                    ch_[r] = ok ? H[fc + i] : NodeHdr{-1, 0, 0};
+                }
             }
         }
         int best_i = 0;
@@ -656,6 +670,7 @@ __device__ __forceinline__ void dev_expand(SpParams& p, int g, int lane, Positio
         prv[k] = i < MAXC ? p.prior[(size_t)g * MAXC + i] : 0.f;
         lmv[k] = i < MAXC ? p.legal_mv[(size_t)g * MAXC + i] : (uint16_t)0;
     }
+    const unsigned long long sc_sims = p.slot_cnt[(size_t)g * 2], sc_evals = p.slot_cnt[(size_t)g * 2 + 1];
     if (cs.status != ST_ACTIVE || cs.leaf_kind == LK_NONE) return;
     const size_t nb = (size_t)g * p.node_cap;
     int32_t* N = p.N + nb;
@@ -729,8 +744,10 @@ __device__ __forceinline__ void dev_expand(SpParams& p, int g, int lane, Positio
             c.err = cs.err | err;
             atomicOr(&p.cnt->err, (int)err);
         }
-        atomicAdd(&p.cnt->sims_done, 1ULL);
-        if (kind == LK_EVAL) atomicAdd(&p.cnt->nn_evals, 1ULL);
+        // per-slot counters (summed by the host): 256 waves adding to ONE global counter at the same moment serialise
+        // in the L2 atomic unit, and this wave's next loads queue behind its own atomics (in-order vmcnt)
+        p.slot_cnt[(size_t)g * 2] = sc_sims + 1ULL;
+        if (kind == LK_EVAL) p.slot_cnt[(size_t)g * 2 + 1] = sc_evals + 1ULL;
     }
     if (sim < p.rollout) return;
 
@@ -876,9 +893,11 @@ __global__ __launch_bounds__(64) void k_mcts(SpParams p, int do_expand, int do_s
     __shared__ uint16_t s_ps[DEPTH_LDS];
     SC_STAMP(0);
     if (do_expand) {
+        // No fence between the two halves: the block is ONE wavefront, whose vector-memory operations reach the cache
+        // hierarchy in program order, so the selection below reads what the expansion above stored (statistics of the
+        // path, control block, tree headers) without first waiting for every store to be acknowledged (~4 k cycles).
         dev_expand(p, g, lane, &s_pos);
-        __threadfence_block();
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();
     }
     SC_STAMP(1);
     if (do_select) dev_select(p, g, lane, s_stage, s_moves, &s_pos, s_ps, s_hist);

@@ -75,6 +75,7 @@ struct SpParams {
     float* t_cq;
     float* t_cu;
     Counters* cnt;
+    unsigned long long* slot_cnt;   // [n_slots][2] simulations / network evaluations per slot (no contended atomics on the hot path)
     // fused value-head tail (NET evaluator): split-K partials of value_head.ffn.0 + fp32 parameters
     int vf_fused, vf_ksplit;
     const float* vpart;
