@@ -261,11 +261,12 @@ constexpr int DEPTH_LDS = 1024;  // path entries tracked in LDS (a deeper path s
     } while (0)
 
 __device__ __forceinline__ void dev_select(const SpParams& p, int g, int lane, int8_t* s_stage, move_t* s_moves, Position* s_leaf_p,
-                                        uint16_t* s_ps, Position* s_hist) {
+                                        uint16_t* s_ps, Position* s_hist, const GameCtl& cs_pre, bool cs_pre_valid) {
     Position& s_leaf = *s_leaf_p;
     SC_STAMP(2);
     GameCtl& c = p.ctl[g];
-    const GameCtl cs = uniform(c);  // one 64-byte fetch instead of a chain of dependent field loads
+    GameCtl cs = cs_pre;
+    if (!cs_pre_valid) cs = uniform(c);  // one 64-byte fetch instead of a chain of dependent field loads
     // the root position and the root header ride in the same round trip (their addresses depend on g only)
     const Position root = uniform(p.tpos[(size_t)g * p.tpos_cap]);
     NodeHdr hdr = uniform(p.H[(size_t)g * p.node_cap]);
@@ -656,7 +657,9 @@ __device__ inline float value_from_partials(const SpParams& p, int g, int lane) 
     return v * (float)(meta[0] * 2 - 1);
 }
 
-__device__ __forceinline__ void dev_expand(SpParams& p, int g, int lane, Position* s_np_p) {
+// cs_out / cs_valid: the control block as this function leaves it, handed to dev_select in registers (a reload would be
+// a load of words stored a few instructions earlier); not valid after a ply transition
+__device__ __forceinline__ void dev_expand(SpParams& p, int g, int lane, Position* s_np_p, GameCtl& cs_out, bool& cs_valid) {
     Position& s_np = *s_np_p;
     GameCtl& c = p.ctl[g];
     const GameCtl cs = uniform(c);  // one 64-byte fetch instead of a chain of dependent field loads
@@ -671,6 +674,8 @@ __device__ __forceinline__ void dev_expand(SpParams& p, int g, int lane, Positio
         lmv[k] = i < MAXC ? p.legal_mv[(size_t)g * MAXC + i] : (uint16_t)0;
     }
     const unsigned long long sc_sims = p.slot_cnt[(size_t)g * 2], sc_evals = p.slot_cnt[(size_t)g * 2 + 1];
+    cs_out = cs;
+    cs_valid = true;
     if (cs.status != ST_ACTIVE || cs.leaf_kind == LK_NONE) return;
     const size_t nb = (size_t)g * p.node_cap;
     int32_t* N = p.N + nb;
@@ -749,7 +754,13 @@ __device__ __forceinline__ void dev_expand(SpParams& p, int g, int lane, Positio
         p.slot_cnt[(size_t)g * 2] = sc_sims + 1ULL;
         if (kind == LK_EVAL) p.slot_cnt[(size_t)g * 2 + 1] = sc_evals + 1ULL;
     }
+    cs_out.n_nodes = n_nodes;
+    cs_out.n_exp = n_exp;
+    cs_out.sim = sim;
+    cs_out.leaf_kind = LK_NONE;
+    cs_out.err = cs.err | err;
     if (sim < p.rollout) return;
+    cs_valid = false;
 
     // ---------------- end of this ply's search (main.rs:198-233)
     __threadfence_block();
@@ -892,15 +903,17 @@ __global__ __launch_bounds__(64) void k_mcts(SpParams p, int do_expand, int do_s
     __shared__ Position s_hist[8];
     __shared__ uint16_t s_ps[DEPTH_LDS];
     SC_STAMP(0);
+    GameCtl cs_pre{};
+    bool cs_pre_valid = false;
     if (do_expand) {
         // No fence between the two halves: the block is ONE wavefront, whose vector-memory operations reach the cache
         // hierarchy in program order, so the selection below reads what the expansion above stored (statistics of the
         // path, control block, tree headers) without first waiting for every store to be acknowledged (~4 k cycles).
-        dev_expand(p, g, lane, &s_pos);
+        dev_expand(p, g, lane, &s_pos, cs_pre, cs_pre_valid);
         __builtin_amdgcn_wave_barrier();
     }
     SC_STAMP(1);
-    if (do_select) dev_select(p, g, lane, s_stage, s_moves, &s_pos, s_ps, s_hist);
+    if (do_select) dev_select(p, g, lane, s_stage, s_moves, &s_pos, s_ps, s_hist, cs_pre, cs_pre_valid);
 }
 
 // ------------------------------------------------------------------ sc_selfplay_set_position
