@@ -1,6 +1,10 @@
 // nn_kernels.hip -- translation unit of the network kernels.
 #include "nn_kernels.hpp"
 #include "nn_tower32.hpp"
+#ifndef SC_T32_RS
+#define SC_T32_RS 12   // narrow trunk: 12-slot weight ring, all 9 taps of a conv unrolled (no tap-group loop: measured
+#define SC_T32_TPI 9   // -4 % cycles, -1 % wall over groups of 3; experiment builds may override)
+#endif
 
 #include <stdlib.h>
 
@@ -35,7 +39,7 @@ const char* nn_init() {
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scnn::k_tower32<128, 8, 1>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             scnn::tower32_lds_bytes(128));
     if (e != hipSuccess) return hipGetErrorString(e);
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scnn::k_tower32<128, 12, 3>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scnn::k_tower32<128, SC_T32_RS, SC_T32_TPI>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             scnn::tower32_lds_bytes(128));
     if (e != hipSuccess) return hipGetErrorString(e);
 #ifdef SC_EXP
@@ -58,7 +62,7 @@ void tower(const scnn::TowerArgs& a, hipStream_t s) {
         if (a.net.C == 256)
             hipLaunchKernelGGL((scnn::k_tower32<256, 8, 1>), dim3(a.n_pos), dim3(256), scnn::tower32_lds_bytes(256), s, b);
         else if (ring == 12)
-            hipLaunchKernelGGL((scnn::k_tower32<128, 12, 3>), dim3(a.n_pos), dim3(256), scnn::tower32_lds_bytes(128), s, b);
+            hipLaunchKernelGGL((scnn::k_tower32<128, SC_T32_RS, SC_T32_TPI>), dim3(a.n_pos), dim3(256), scnn::tower32_lds_bytes(128), s, b);
         else
             hipLaunchKernelGGL((scnn::k_tower32<128, 8, 1>), dim3(a.n_pos), dim3(256), scnn::tower32_lds_bytes(128), s, b);
     } else if (a.net.C == 256)

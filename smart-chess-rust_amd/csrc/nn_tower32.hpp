@@ -95,7 +95,10 @@ __device__ __forceinline__ void acc_init(f32x16 (&acc)[CT][2], const ChP<CT>& B)
 // Ring / carry semantics as conv_mma (nn_kernels.hpp): RS slots of one k-step each, loads run RS-1 steps ahead,
 // with PRE the first RS-1 slots were filled by the previous layer's loop (its last prefetches go to `next_first`,
 // a byte offset relative to ITS weights).  AB image-fragment buffers, reads AB-1 steps ahead.
-template <int CIN, int TAPS, int CT, int TILES, int CP, int RS, int TPI, bool PRE, int AB = 4>
+#ifndef SC_T32_AB
+#define SC_T32_AB 4
+#endif
+template <int CIN, int TAPS, int CT, int TILES, int CP, int RS, int TPI, bool PRE, int AB = SC_T32_AB>
 __device__ __forceinline__ void conv_mma32(int xoff, const bf16_t* __restrict__ Wp, int wave_u, int lane, const int (&px)[2],
                                            f32x16 (&acc)[CT][2], bf16x8 (&bq)[RS][CT], int next_first) {
     constexpr int KPT = CIN / 16;          // k-steps per tap
