@@ -11,12 +11,19 @@
 
 #include <algorithm>
 #include <string>
+#include <initializer_list>
 #include <vector>
 
 #include "../../include/sc_engine.h"
 #include "launchers.hpp"
 #include "trace_json.hpp"
 #include "weights.hpp"
+
+// cleanup paths: free a list of device pointers, ignoring errors
+static void dfree(std::initializer_list<void*> ptrs) {
+    for (void* q : ptrs)
+        if (q) (void)hipFree(q);
+}
 
 static thread_local std::string g_err;
 static int fail(const std::string& m, int code = -1) {
@@ -56,8 +63,8 @@ struct sc_engine {
 };
 
 static void engine_free_scratch(sc_engine* e) {
-    (void)hipFree(e->d_boards); hipFree(e->d_meta); hipFree(e->d_lidx); hipFree(e->d_nlegal); hipFree(e->d_prior);
-    (void)hipFree(e->d_value); hipFree(e->d_logp); hipFree(e->d_hval); hipFree(e->d_vpart); hipFree(e->d_dbg);
+    dfree({e->d_boards, e->d_meta, e->d_lidx, e->d_nlegal, e->d_prior});
+    dfree({e->d_value, e->d_logp, e->d_hval, e->d_vpart, e->d_dbg});
     e->d_boards = nullptr; e->d_meta = nullptr; e->d_lidx = nullptr; e->d_nlegal = nullptr; e->d_prior = nullptr;
     e->d_value = nullptr; e->d_logp = nullptr; e->d_hval = nullptr; e->d_vpart = nullptr; e->d_dbg = nullptr;
     e->cap = 0;
@@ -171,12 +178,12 @@ int sc_engine_create(const sc_net_config* cfg, const char* weights_path, int dev
 
 void sc_engine_destroy(sc_engine* e) {
     if (!e) return;
-    hipSetDevice(e->device);
-    hipStreamSynchronize(e->stream);
+    (void)hipSetDevice(e->device);
+    (void)hipStreamSynchronize(e->stream);
     engine_free_scratch(e);
-    (void)hipFree(e->d_wb);
-    (void)hipFree(e->d_wf);
-    hipStreamDestroy(e->stream);
+    dfree({e->d_wb});
+    dfree({e->d_wf});
+    (void)hipStreamDestroy(e->stream);
     delete e;
 }
 
@@ -304,8 +311,8 @@ int sc_encode_positions(sc_engine* e, int device_id, int n, const uint16_t* move
     if (legal_idx) HIPOK(hipMemcpy(legal_idx, d_li, (size_t)n * 224 * 2, hipMemcpyDeviceToHost));
     if (n_legal) HIPOK(hipMemcpy(n_legal, d_nl, (size_t)n * 4, hipMemcpyDeviceToHost));
     if (outcome) HIPOK(hipMemcpy(outcome, d_out, (size_t)n * 16, hipMemcpyDeviceToHost));
-    (void)hipFree(d_moves); hipFree(d_off); hipFree(d_hist); hipFree(d_boards); hipFree(d_meta); hipFree(d_nl); hipFree(d_out);
-    (void)hipFree(d_lm); hipFree(d_li);
+    dfree({d_moves, d_off, d_hist, d_boards, d_meta, d_nl, d_out});
+    dfree({d_lm, d_li});
     return 0;
 }
 
@@ -396,8 +403,8 @@ int sc_encode_steps(sc_engine* e, int device_id, int n_games, const uint16_t* mo
             else if (flags[i] & 2) status[g] = -(ply + 1);
         }
     }
-    (void)hipFree(d_moves); hipFree(d_cmv); hipFree(d_cn); hipFree(d_coff); hipFree(d_start); hipFree(d_len); hipFree(d_hist);
-    (void)hipFree(d_boards); hipFree(d_meta); hipFree(d_nl); hipFree(d_flags); hipFree(d_out); hipFree(d_lm); hipFree(d_li); hipFree(d_dist);
+    dfree({d_moves, d_cmv, d_cn, d_coff, d_start, d_len, d_hist});
+    dfree({d_boards, d_meta, d_nl, d_flags, d_out, d_lm, d_li, d_dist});
     return 0;
 }
 
@@ -579,13 +586,13 @@ int sc_selfplay_create(sc_engine* e, int device_id, const sc_selfplay_config* cf
 
 void sc_selfplay_destroy(sc_selfplay* sp) {
     if (!sp) return;
-    hipSetDevice(sp->device);
-    if (sp->stream) hipStreamSynchronize(sp->stream);
-    for (void* a : sp->allocs) hipFree(a);
-    for (hipEvent_t ev : sp->ev) hipEventDestroy(ev);
-    if (sp->ev_begin) hipEventDestroy(sp->ev_begin);
-    if (sp->ev_end) hipEventDestroy(sp->ev_end);
-    if (sp->own_stream) hipStreamDestroy(sp->stream);
+    (void)hipSetDevice(sp->device);
+    if (sp->stream) (void)hipStreamSynchronize(sp->stream);
+    for (void* a : sp->allocs) (void)hipFree(a);
+    for (hipEvent_t ev : sp->ev) (void)hipEventDestroy(ev);
+    if (sp->ev_begin) (void)hipEventDestroy(sp->ev_begin);
+    if (sp->ev_end) (void)hipEventDestroy(sp->ev_end);
+    if (sp->own_stream) (void)hipStreamDestroy(sp->stream);
     delete sp;
 }
 
@@ -932,7 +939,7 @@ int sc_selfplay_set_position(sc_selfplay* sp, int slot, const uint16_t* moves, i
     scl::set_position(sp->p, slot, d_moves, n_moves, sp->stream);
     HIPOK(hipGetLastError());
     HIPOK(hipStreamSynchronize(sp->stream));
-    (void)hipFree(d_moves);
+    dfree({d_moves});
     return 0;
 }
 
