@@ -41,3 +41,19 @@ def test_cli_writes_reference_traces(tmp_path, orc):
             assert [c[0] for c in kids] == st.legal_uci() and sum(c[1] for c in kids) == 23
             assert len(kids[0]) == 4
             st.push(mv)
+
+
+@pytest.mark.gpu
+def test_cli_groups_write_the_same_games(tmp_path):
+    """--groups 2 (two interleaved handles on two HIP streams) plays the same games as one handle: a game's moves depend
+    only on its id and the seed, not on the slot or group it lands in"""
+    a, b = tmp_path / "a", tmp_path / "b"
+    a.mkdir()
+    b.mkdir()
+    common = ["-d", "cuda", "--rollout-num", "16", "-n", "8", "--temperature", "0", "--cpuct", "2", "--temperature-switch", "2",
+              "--games", "8", "--blocks", "1", "--channels", "128", "--seed", "11"]
+    r1 = _run(*common, "-t", str(a / "trace{}.json"), "--concurrency", "8")
+    r2 = _run(*common, "-t", str(b / "trace{}.json"), "--concurrency", "8", "--groups", "2")
+    assert r1.returncode == 0 and r2.returncode == 0, (r1.stderr, r2.stderr)
+    for k in range(1, 9):
+        assert open(str(a / f"trace{k}.json")).read() == open(str(b / f"trace{k}.json")).read(), k
