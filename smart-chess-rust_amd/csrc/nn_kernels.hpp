@@ -244,9 +244,11 @@ __device__ __forceinline__ void ln_load(LnP<NTW>& P, const float* __restrict__ b
         P.e[i] = beta[c0 + i];
     }
 }
+// ReLU is one v_max_f32 (NaN -> 0, unlike torch.relu): NaNs are caught at the LayerNorm variances (`bad`) and poison the
+// kernel's outputs at the end, as in nn_tower32.hpp.
 template <int NTW>
 __device__ inline void bias_layernorm(f32x4 (&acc)[4][NTW], const LnP<NTW>& P, int count, bool relu, int wave, int lane,
-                                      float* s_stat2, float* s_mr, int& parity) {
+                                      float* s_stat2, float* s_mr, int& parity, int& bad) {
     // two alternating partial-sum buffers: the buffer written here was last read two LayerNorms ago, and every
     // wave has passed the barrier of the LayerNorm in between since then -> one barrier per LayerNorm suffices
     float* s_stat = s_stat2 + (parity & 1) * 512;
@@ -290,8 +292,9 @@ __device__ inline void bias_layernorm(f32x4 (&acc)[4][NTW], const LnP<NTW>& P, i
         const float inv = 1.0f / (float)count;
         float mean = s * inv;
         float var = q * inv - mean * mean;
-        var = var < 0.f ? 0.f : var;
-        float rstd = 1.0f / sqrtf(var + 1e-6f);
+        bad |= (var != var) ? 1 : 0;
+        var = fmaxf(var, 0.f);
+        float rstd = __frsqrt_rn(var + 1e-6f);
         // wave-private broadcast through LDS (DS ops of one wave execute in order; no barrier needed)
         reinterpret_cast<float2*>(s_mr)[wave * 64 + row_own] = make_float2(mean, rstd);
     }
@@ -304,7 +307,7 @@ __device__ inline void bias_layernorm(f32x4 (&acc)[4][NTW], const LnP<NTW>& P, i
 #pragma unroll
             for (int i = 0; i < NTW; i++) {
                 float y = (acc[mt][i][r] - mr.x) * mr.y * P.g[i] + P.e[i];
-                acc[mt][i][r] = (relu && y < 0.f) ? 0.f : y;
+                acc[mt][i][r] = relu ? fmaxf(y, 0.f) : y;
             }
         }
 }
@@ -391,6 +394,7 @@ __global__ __launch_bounds__(256, 1) void k_tower(TowerArgs A) {
     // that free) so that the conv loops keep only accumulators + operand rings in registers.
     f32x4 acc[4][NTW];
     int ln_parity = 0;
+    int bad = 0;   // a LayerNorm saw a NaN variance
     auto store_res = [&]() {
         const int c0 = chan0<NTW>(wave, lane);
 #pragma unroll
@@ -427,7 +431,7 @@ __global__ __launch_bounds__(256, 1) void k_tower(TowerArgs A) {
         const bf16_t* w0 = net.wb + net.o_stem;
         const int to_blk0 = (int)((net.wb + net.o_blocks) - w0) * 2 + t0 * GRP_BYTES;
         conv_mma<128, 9, NTW, NT, true, CP, RS, TPI, false>(0, w0, wave, lane, t0, acc, ring, to_blk0);
-        bias_layernorm<NTW>(acc, P, C, true, wave, lane, s_stat, s_mr, ln_parity);
+        bias_layernorm<NTW>(acc, P, C, true, wave, lane, s_stat, s_mr, ln_parity, bad);
     }
     store_res();
     store_image<NTW, true, CP>(acc, Xa, wave, lane);  // every wave passed the LN barriers: the input image is dead
@@ -490,7 +494,7 @@ __global__ __launch_bounds__(256, 1) void k_tower(TowerArgs A) {
             for (int i = 0; i < NTW; i++) b2v[i] = b2[c0 + i];
         }
         __builtin_amdgcn_sched_barrier(0);
-        bias_layernorm<NTW>(acc, P1, C, true, wave, lane, s_stat, s_mr, ln_parity);
+        bias_layernorm<NTW>(acc, P1, C, true, wave, lane, s_stat, s_mr, ln_parity, bad);
         store_image<NTW, true, CP>(acc, Xa, wave, lane);
         __syncthreads();
         mark(1);
@@ -510,7 +514,7 @@ __global__ __launch_bounds__(256, 1) void k_tower(TowerArgs A) {
         VecW<C / 2, NTW> w2;
         vec_w_load<C / 2, NTW, NT>(w2, wb + (size_t)18 * C * C + (size_t)C * (C / 2), wave * NTW, lane);
         __builtin_amdgcn_sched_barrier(0);  // keep the loads HERE (the scheduler would sink them to their use)
-        bias_layernorm<NTW>(acc, P2, C, false, wave, lane, s_stat, s_mr, ln_parity);
+        bias_layernorm<NTW>(acc, P2, C, false, wave, lane, s_stat, s_mr, ln_parity, bad);
         mark(3);
         // global average pool over the 64 pixels
         {
@@ -546,7 +550,7 @@ __global__ __launch_bounds__(256, 1) void k_tower(TowerArgs A) {
                     const int tile = FULL1 ? i : wave * NTW1 + i;
                     const int j = (tile / PW1) * (16 * PW1) + (lane & 15) * PW1 + (tile % PW1);
                     float v = h[i][0] + b1v[i];
-                    s_hid[j] = f2bf(v > 0.f ? v : 0.f);
+                    s_hid[j] = f2bf(fmaxf(v, 0.f));
                 }
             }
         }
@@ -583,7 +587,7 @@ __global__ __launch_bounds__(256, 1) void k_tower(TowerArgs A) {
 #pragma unroll
                     for (int i = 0; i < NTW; i++) {
                         float y = acc[mt][i][r] * scl[i] + rv[i];
-                        acc[mt][i][r] = y > 0.f ? y : 0.f;
+                        acc[mt][i][r] = fmaxf(y, 0.f);
                     }
                 }
         }
@@ -611,7 +615,7 @@ __global__ __launch_bounds__(256, 1) void k_tower(TowerArgs A) {
         __builtin_amdgcn_sched_barrier(0);
         bf16x8 hr[4][4];
         conv_mma<C, 1, 4, 16, true, CP, 4, 1>(0, net.wb + net.o_vconv, wave, lane, 0, hv, hr, 0);
-        bias_layernorm<4>(hv, P, HEAD, true, wave, lane, s_stat, s_mr, ln_parity);
+        bias_layernorm<4>(hv, P, HEAD, true, wave, lane, s_stat, s_mr, ln_parity, bad);
         const int c0 = chan0<4>(wave, lane);
 #pragma unroll
         for (int mt = 0; mt < 4; mt++)
@@ -637,7 +641,7 @@ __global__ __launch_bounds__(256, 1) void k_tower(TowerArgs A) {
         __builtin_amdgcn_sched_barrier(0);
         bf16x8 hr[4][4];
         conv_mma<C, 1, 4, 16, true, CP, 4, 1>(0, net.wb + net.o_pconv1, wave, lane, 0, hp, hr, 0);
-        bias_layernorm<4>(hp, P, HEAD, false, wave, lane, s_stat, s_mr, ln_parity);
+        bias_layernorm<4>(hp, P, HEAD, false, wave, lane, s_stat, s_mr, ln_parity, bad);
         store_image<4, false, HP>(hp, Xh, wave, lane);
     }
     __syncthreads();
@@ -654,7 +658,7 @@ __global__ __launch_bounds__(256, 1) void k_tower(TowerArgs A) {
         bf16x8 hr[4][2];
         conv_mma<HEAD, 1, 2, 8, false, HP, 4, 1>(XA_BYTES, net.wb + net.o_pconv2, wave, lane, 0, z, hr, 0);
         // padded channels (>=73) have zero weights, bias, gamma, beta: they add 0 to both LN sums
-        bias_layernorm<2>(z, P, 73, false, wave, lane, s_stat, s_mr, ln_parity);
+        bias_layernorm<2>(z, P, 73, false, wave, lane, s_stat, s_mr, ln_parity, bad);
         __syncthreads();  // everyone is done with Xa/Xh: the logits may overwrite the image area
         const int c0 = chan0<2>(wave, lane);
 #pragma unroll
@@ -666,6 +670,10 @@ __global__ __launch_bounds__(256, 1) void k_tower(TowerArgs A) {
                     int ch = c0 + i, p = row2pix(mt * 16 + (lane >> 4) * 4 + r);
                     if (ch < 73) s_z[ch * 64 + p] = z[mt][i][r];  // Flatten is channel-major (module.py:75)
                 }
+        if (bad) {   // make the NaN visible in the priors and (through the value features) in the value
+            s_z[lane] = __builtin_nanf("");
+            A.hval[(size_t)pos * 64 * HEAD + tid] = 0x7fc0;
+        }
     }
     __syncthreads();
     // ---- log_softmax over 4672 (module.py:80), then the legal-move gather of torch.rs:148-175
