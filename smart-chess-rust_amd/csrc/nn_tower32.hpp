@@ -326,7 +326,10 @@ constexpr int tower32_lds_bytes(int C) {
 }
 
 template <int C, int RS, int TPI>
-__global__ __launch_bounds__(256, 1) void k_tower32(TowerArgs A) {
+#ifndef SC_T32_OCC
+#define SC_T32_OCC 1
+#endif
+__global__ __launch_bounds__(256, SC_T32_OCC) void k_tower32(TowerArgs A) {
     constexpr int CT = C / 128;        // 32-channel tiles per wave in the trunk
     constexpr int TILES = C / 32;
     constexpr int CP = C + 8;          // image pixel stride (elements): (C+8)*2 B is an odd multiple of 16 B

@@ -486,3 +486,23 @@ def _pushed(orc, moves):
     for m in moves:
         st.push(m)
     return st
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("C,slots,games,R,steps,temp,tsw,noise", [
+    (128, 1, 1, 1, 1, 0.0, 0, True), (128, 3, 7, 5, 9, 1.0, 100, True), (256, 255, 255, 3, 2, 0.0, 1, False),
+    (128, 257, 300, 4, 3, 0.5, 2, True), (128, 513, 513, 2, 2, 0.0, 0, True), (128, 17, 40, 9, 30, 0.0, 4, True)])
+def test_selfplay_edge_configurations(scamd, C, slots, games, R, steps, temp, tsw, noise):
+    """ragged sizes: one slot, more games than slots, more slots than CUs, rollout 1, sampling at every ply"""
+    eng = scamd.Engine(2, C, seed=1)
+    sp = scamd.SelfPlay(eng, n_slots=slots, n_games=games, rollout_num=R, num_steps=steps, temperature=temp,
+                        temperature_switch=tsw, with_noise=noise, seed=3, outcome_gate=0)
+    sp.run()
+    st = sp.stats()
+    assert st["games_finished"] == games and st["error_flags"] == 0 and st["games_active"] == 0
+    for g in range(games):
+        t = sp.trace(g)
+        assert t is not None and 1 <= len(t["steps"]) <= steps
+        assert all(sum(c[1] for c in s[2]) == R - 1 for s in t["steps"])
+    sp.close()
+    eng.close()
