@@ -39,6 +39,29 @@ __device__ inline bf16_t f2bf(float x) {
 }
 __device__ inline float bf2f(bf16_t u) { return __builtin_bit_cast(float, (uint32_t)u << 16); }
 
+// Wave-wide sum / max with the result in every lane: four DPP steps inside each row of 16 lanes (quad_perm,
+// row_half_mirror, row_mirror -- plain VALU moves) and four readlanes, instead of six dependent trips through the LDS
+// crossbar (ds_bpermute).  Fixed order, so results are reproducible.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float readlane_f(float x, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), l)); }
+__device__ __forceinline__ float wave_sum64(float v) {
+    v += dpp_f<0xB1>(v);
+    v += dpp_f<0x4E>(v);
+    v += dpp_f<0x141>(v);
+    v += dpp_f<0x140>(v);
+    return (readlane_f(v, 0) + readlane_f(v, 16)) + (readlane_f(v, 32) + readlane_f(v, 48));
+}
+__device__ __forceinline__ float wave_max64(float v) {
+    v = fmaxf(v, dpp_f<0xB1>(v));
+    v = fmaxf(v, dpp_f<0x4E>(v));
+    v = fmaxf(v, dpp_f<0x141>(v));
+    v = fmaxf(v, dpp_f<0x140>(v));
+    return fmaxf(fmaxf(readlane_f(v, 0), readlane_f(v, 16)), fmaxf(readlane_f(v, 32), readlane_f(v, 48)));
+}
+
 // haloed image index of pixel p (0..63)
 __device__ inline int hidx(int p) { return ((p >> 3) + 1) * 10 + (p & 7) + 1; }
 // GEMM row (0..63) -> board pixel.  Rows 8..15 of every 16-row MFMA tile take the files of their rank rotated
@@ -679,13 +702,13 @@ __global__ __launch_bounds__(256, 1) void k_tower(TowerArgs A) {
     // ---- log_softmax over 4672 (module.py:80), then the legal-move gather of torch.rs:148-175
     float mx = -3.0e38f;
     for (int i = tid; i < 4672; i += 256) mx = fmaxf(mx, s_z[i]);
-    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    mx = wave_max64(mx);
     if (lane == 0) s_red[wave] = mx;
     __syncthreads();
     mx = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
     float se = 0.f;
     for (int i = tid; i < 4672; i += 256) se += __expf(s_z[i] - mx);
-    for (int o = 32; o > 0; o >>= 1) se += __shfl_xor(se, o, 64);
+    se = wave_sum64(se);
     if (lane == 0) s_red[4 + wave] = se;
     __syncthreads();
     se = (s_red[4] + s_red[5]) + (s_red[6] + s_red[7]);
@@ -700,7 +723,7 @@ __global__ __launch_bounds__(256, 1) void k_tower(TowerArgs A) {
         float e = 0.f;
         if (tid < n) e = __expf(s_z[li[tid]] - lse);  // n <= 218 < 256 threads
         float s = e;
-        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        s = wave_sum64(s);
         __syncthreads();
         if (lane == 0) s_red[wave] = s;
         __syncthreads();

@@ -279,9 +279,7 @@ __device__ inline void store_image32(const f32x16 (&acc)[CT][2], const int (&pix
 // lane's contribution reaches every sum exactly once.  Lanes with the bit set keep the upper W values (W = 0: a
 // single value is left, plain exchange-add).  Lane j of a half ends with value index j (32 values) or j>>1 (16).
 template <int CTRL>
-__device__ __forceinline__ float dpp_mov(float x) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, false));
-}
+__device__ __forceinline__ float dpp_mov(float x) { return dpp_f<CTRL>(x); }
 template <int LVL>
 __device__ __forceinline__ float pool_xchg(float x) {
     if constexpr (LVL == 0) return __shfl_xor(x, 16, 64);
@@ -706,13 +704,13 @@ __global__ __launch_bounds__(256, SC_T32_OCC) void k_tower32(TowerArgs A) {
     // ---- log_softmax over 4672 (module.py:80), then the legal-move gather of torch.rs:148-175
     float mx = -3.0e38f;
     for (int k = tid; k < 4672; k += 256) mx = fmaxf(mx, s_z[k]);
-    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    mx = wave_max64(mx);
     if (lane == 0) s_red[wave] = mx;
     __syncthreads();
     mx = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
     float se = 0.f;
     for (int k = tid; k < 4672; k += 256) se += __expf(s_z[k] - mx);
-    for (int o = 32; o > 0; o >>= 1) se += __shfl_xor(se, o, 64);
+    se = wave_sum64(se);
     if (lane == 0) s_red[4 + wave] = se;
     __syncthreads();
     se = (s_red[4] + s_red[5]) + (s_red[6] + s_red[7]);
@@ -728,7 +726,7 @@ __global__ __launch_bounds__(256, SC_T32_OCC) void k_tower32(TowerArgs A) {
         float e = 0.f;
         if (tid < n) e = __expf(s_z[li[tid]] - lse);  // n <= 218 < 256 threads
         float s = e;
-        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        s = wave_sum64(s);
         __syncthreads();
         if (lane == 0) s_red[wave] = s;
         __syncthreads();
