@@ -155,7 +155,8 @@ int sc_engine_create(const sc_net_config* cfg, const char* weights_path, int dev
     // 32x32x16 kernel; the wide trunk is matrix-pipe dense enough that the chip holds a ~13 % lower clock on that
     // MFMA shape, so it keeps the 16x16x32 kernel.  SC_TOWER_V=1|2 forces one of them (developer switch).
     const int tv = getenv("SC_TOWER_V") ? atoi(getenv("SC_TOWER_V")) : 0;
-    const bool v32 = tv == 2 || (tv != 1 && hw.C == 128);
+    bool v32 = tv == 2 || (tv != 1 && hw.C == 128);
+    if (!scl::tower_variant_available(hw.C, v32)) v32 = hw.C == 128;   // the forced variant exists in experiment builds only
     scw::Packed pk = scw::pack(hw, v32);
     sc_engine* e = new sc_engine();
     e->device = device_id;

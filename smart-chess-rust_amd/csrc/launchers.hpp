@@ -20,6 +20,7 @@ void steps_dist(int n, const uint16_t* legal_mv, const int32_t* n_legal, const u
 // nn_kernels.hip
 const char* nn_init();  // sets kernel attributes; returns error text or nullptr
 size_t tower_lds_bytes(int C);
+bool tower_variant_available(int C, bool tower32);   // production builds carry one tower kernel per trunk width
 void tower(const scnn::TowerArgs& a, hipStream_t s);
 void value_fc1(const scnn::Fc1Args& a, hipStream_t s);
 void value_finish(const scnn::VfinArgs& a, hipStream_t s);

@@ -23,26 +23,23 @@ size_t tower16_lds_bytes(int C) {
     size_t rs = std::max<size_t>(64 * rp * 4, 64 * hp * 2);
     return 100 * cp * 2 + rs + 1024 * 4 + 768 * 4 + 8 * 4 + 4 * 64 * 8;
 }
+// Production build: ONE tower kernel per trunk width (see engine.hip / DESIGN.md 3.2 for how they were chosen).
+// Experiment builds (-DSC_EXP, tools/build_exp.sh) also carry the other variant of each width for A/B runs
+// (SC_TOWER_V=1|2 at engine creation picks the weight packing, and with it the kernel).
 const char* nn_init() {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scnn::k_tower<256, 4, 1>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)tower_lds_bytes(256));
     if (e != hipSuccess) return hipGetErrorString(e);
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scnn::k_tower<128, 4, 1>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)tower_lds_bytes(128));
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scnn::k_tower32<128, SC_T32_RS, SC_T32_TPI>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            scnn::tower32_lds_bytes(128));
     if (e != hipSuccess) return hipGetErrorString(e);
+#ifdef SC_EXP
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scnn::k_tower<128, 12, 3>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)tower_lds_bytes(128));
     if (e != hipSuccess) return hipGetErrorString(e);
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scnn::k_tower32<256, 8, 1>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             scnn::tower32_lds_bytes(256));
     if (e != hipSuccess) return hipGetErrorString(e);
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scnn::k_tower32<128, 8, 1>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            scnn::tower32_lds_bytes(128));
-    if (e != hipSuccess) return hipGetErrorString(e);
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scnn::k_tower32<128, SC_T32_RS, SC_T32_TPI>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            scnn::tower32_lds_bytes(128));
-    if (e != hipSuccess) return hipGetErrorString(e);
-#ifdef SC_EXP
     if (getenv("SC_EXP_WAND")) {
         int v = (int)strtol(getenv("SC_EXP_WAND"), nullptr, 0);
         (void)hipMemcpyToSymbol(HIP_SYMBOL(scnn::g_exp_wand), &v, sizeof(int));
@@ -50,27 +47,30 @@ const char* nn_init() {
 #endif
     return nullptr;
 }
+bool tower_variant_available(int C, bool tower32) {
+#ifdef SC_EXP
+    (void)C;
+    (void)tower32;
+    return true;
+#else
+    return tower32 == (C == 128);
+#endif
+}
 void tower(const scnn::TowerArgs& a, hipStream_t s) {
     if (a.n_pos <= 0) return;
-    static const int ring = getenv("SC_TOWER_RING") ? atoi(getenv("SC_TOWER_RING")) : 12;     // experiment knobs
-    static const int stagger = getenv("SC_TOWER_STAGGER") ? atoi(getenv("SC_TOWER_STAGGER")) : 0;
     scnn::TowerArgs b = a;
-    b.stagger = stagger;
-    static const int delay = getenv("SC_TOWER_DELAY") ? atoi(getenv("SC_TOWER_DELAY")) : 0;
-    b.delay = delay;
-    if (a.net.tower32) {
-        if (a.net.C == 256)
-            hipLaunchKernelGGL((scnn::k_tower32<256, 8, 1>), dim3(a.n_pos), dim3(256), scnn::tower32_lds_bytes(256), s, b);
-        else if (ring == 12)
-            hipLaunchKernelGGL((scnn::k_tower32<128, SC_T32_RS, SC_T32_TPI>), dim3(a.n_pos), dim3(256), scnn::tower32_lds_bytes(128), s, b);
-        else
-            hipLaunchKernelGGL((scnn::k_tower32<128, 8, 1>), dim3(a.n_pos), dim3(256), scnn::tower32_lds_bytes(128), s, b);
-    } else if (a.net.C == 256)
+    b.stagger = 0;
+    b.delay = 0;
+    if (a.net.tower32 && a.net.C == 128)
+        hipLaunchKernelGGL((scnn::k_tower32<128, SC_T32_RS, SC_T32_TPI>), dim3(a.n_pos), dim3(256), scnn::tower32_lds_bytes(128), s, b);
+    else if (!a.net.tower32 && a.net.C == 256)
         hipLaunchKernelGGL((scnn::k_tower<256, 4, 1>), dim3(a.n_pos), dim3(256), tower_lds_bytes(256), s, b);
-    else if (ring == 12)
-        hipLaunchKernelGGL((scnn::k_tower<128, 12, 3>), dim3(a.n_pos), dim3(256), tower_lds_bytes(128), s, b);
+#ifdef SC_EXP
+    else if (a.net.tower32)
+        hipLaunchKernelGGL((scnn::k_tower32<256, 8, 1>), dim3(a.n_pos), dim3(256), scnn::tower32_lds_bytes(256), s, b);
     else
-        hipLaunchKernelGGL((scnn::k_tower<128, 4, 1>), dim3(a.n_pos), dim3(256), tower_lds_bytes(128), s, b);
+        hipLaunchKernelGGL((scnn::k_tower<128, 12, 3>), dim3(a.n_pos), dim3(256), tower_lds_bytes(128), s, b);
+#endif
 }
 void value_fc1(const scnn::Fc1Args& a, hipStream_t s) {
     if (a.n_pos <= 0) return;

@@ -7,7 +7,8 @@ L = scamd.lib()
 L.sc_selfplay_debug_cycles.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
 eng = scamd.Engine(10, 128, seed=1)
 G = 256
-sp = scamd.SelfPlay(eng, n_slots=G, n_games=10000, trace_capacity=512, rollout_num=180, num_steps=150, cpuct=2.5, seed=5)
+R = int(os.environ.get("SC_DBG_ROLLOUT", "180"))
+sp = scamd.SelfPlay(eng, n_slots=G, n_games=10000, trace_capacity=512, rollout_num=R, num_steps=150, cpuct=2.5, seed=5)
 sp.enqueue(400)
 L.sc_selfplay_debug_cycles(sp.h, 1, None)
 acc = []
