@@ -58,9 +58,7 @@ bool tower_variant_available(int C, bool tower32) {
 }
 void tower(const scnn::TowerArgs& a, hipStream_t s) {
     if (a.n_pos <= 0) return;
-    scnn::TowerArgs b = a;
-    b.stagger = 0;
-    b.delay = 0;
+    const scnn::TowerArgs& b = a;
     if (a.net.tower32 && a.net.C == 128)
         hipLaunchKernelGGL((scnn::k_tower32<128, SC_T32_RS, SC_T32_TPI>), dim3(a.n_pos), dim3(256), scnn::tower32_lds_bytes(128), s, b);
     else if (!a.net.tower32 && a.net.C == 256)

@@ -385,12 +385,6 @@ __global__ __launch_bounds__(256, 1) void k_tower(TowerArgs A) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform: scalar addressing of the weights
     const NetDev& net = A.net;
 
-    // de-phase the workgroups: all of them stream the same weights, offsetting them in time by a fraction of a
-    // layer spreads their L2 requests over different lines/channels without changing any summation order
-    if (A.delay > 0) {
-        const int n = ((int)(blockIdx.x % 9u) * A.delay) >> 6;
-        for (int i = 0; i < n; i++) __builtin_amdgcn_s_sleep(1);
-    }
     // ---- zero the image (halo stays zero for the whole kernel), then load the 112 input planes
     {
         uint4* z = reinterpret_cast<uint4*>(Xa);
@@ -443,7 +437,8 @@ __global__ __launch_bounds__(256, 1) void k_tower(TowerArgs A) {
     // stem: K = 9 taps x 128 padded input planes (4 k-steps per tap)
     constexpr int SRS = (TPI > 1) ? 4 * TPI : 4;
     static_assert(SRS == RS, "the stem shares the trunk's weight ring (ring carry across layers)");
-    const int t0 = A.stagger ? (int)((blockIdx.x * (unsigned)A.stagger) % (unsigned)(9 / TPI)) : 0;
+    constexpr int t0 = 0;   // taps in natural order (cyclic per-workgroup start offsets were tried: no gain, and they
+                            // break the bitwise independence of a position's result from its slot)
     constexpr int GRP_BYTES = (C / 32) * TPI * NT * 1024;   // bytes of one tap group of a trunk conv
     bf16x8 ring[RS][NTW];                                  // weight prefetch ring, carried from layer to layer
     {

@@ -32,8 +32,6 @@ struct TowerArgs {
     bf16_t* hval;               // [n][64][256] value-head features (input of k_value_fc1)
     float* dbg;                 // optional: [n][64][C] residual stream dump
     int dbg_stage;              // -1: none; 0: after stem; b>=1: after block b; 1000: final latent
-    int stagger;                // experiment: workgroup b starts the 3x3 taps at (b*stagger)%9 (0 = natural order)
-    int delay;                  // workgroup b sleeps (b%9)*delay cycles first: de-phases the workgroups' weight streams
 };
 
 struct Fc1Args {
