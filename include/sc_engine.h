@@ -198,6 +198,14 @@ int sc_selfplay_set_position(sc_selfplay*, int slot, const uint16_t* moves, int 
  * simulations enqueued after the call */
 int sc_selfplay_set_search(sc_selfplay*, float cpuct, float epsilon, int with_noise);
 
+/* One search as a single call: NNPlayer::bestmove's mcts::mcts (src/play.rs:241-252) / chess_play_mcts (src/lib.rs:233-247).
+ * Runs `rollout` simulations from the position reached by `moves` (fresh tree, epsilon 0.15) and returns the number of root
+ * children (< 0: error); child_move / child_n / child_q / child_prior receive up to `cap` of them in python-chess move
+ * order (any may be NULL), *root_q the root's value sum.  For repeated searches keep a handle instead
+ * (sc_selfplay_set_position + sc_selfplay_enqueue_sims + sc_selfplay_get_tree). */
+int sc_search(sc_engine*, const uint16_t* moves, int n_moves, int rollout, float cpuct, int with_noise, uint64_t seed, int cap,
+              uint16_t* child_move, int32_t* child_n, float* child_q, float* child_prior, float* root_q);
+
 /* utility: trace-file JSON writer on caller-provided arrays (no GPU needed) */
 int sc_trace_write_json(const char* path, const sc_trace_info* info, const uint16_t* step_move, const float* step_q,
                         const int32_t* child_off, const uint16_t* child_move, const int32_t* child_n,

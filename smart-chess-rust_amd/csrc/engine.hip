@@ -954,6 +954,53 @@ int sc_selfplay_set_search(sc_selfplay* sp, float cpuct, float epsilon, int with
     return 0;
 }
 
+// One search from a given position: the body of NNPlayer::bestmove (src/play.rs:241-252) / chess_play_mcts
+// (src/lib.rs:233-247) as a single call; see include/sc_engine.h
+int sc_search(sc_engine* e, const uint16_t* moves, int n_moves, int rollout, float cpuct, int with_noise, uint64_t seed,
+              int cap, uint16_t* child_move, int32_t* child_n, float* child_q, float* child_prior, float* root_q) {
+    if (!e || rollout < 1 || rollout > 60000 || cap < 0) return fail("bad argument");
+    sc_selfplay_config c{};
+    c.n_slots = 1;
+    c.n_games = 1;
+    c.rollout_num = 60000;     // the per-ply budget of the self-play driver: never reached here
+    c.num_steps = 4000;
+    c.cpuct = cpuct;
+    c.epsilon = 0.15f;         // mcts::mcts(.., 0.15, noise) at both call sites
+    c.with_noise = with_noise ? 1 : 0;
+    c.outcome_gate = 1 << 30;
+    c.evaluator = SC_EVAL_NET;
+    c.seed = seed;
+    sc_selfplay* sp = nullptr;
+    int rc = sc_selfplay_create(e, e->device, &c, &sp);
+    if (rc) return rc;
+    rc = sc_selfplay_set_position(sp, 0, moves, n_moves);
+    if (!rc) rc = sc_selfplay_enqueue_sims(sp, rollout);
+    int n_children = 0;
+    if (!rc) {
+        std::vector<int32_t> n(1 + 224), fc(1 + 224), nc(1 + 224);
+        std::vector<float> q(1 + 224), pr(1 + 224);
+        std::vector<uint16_t> mv(1 + 224);
+        int nn = sc_selfplay_get_tree(sp, 0, 1 + 224, n.data(), q.data(), nullptr, pr.data(), mv.data(), fc.data(), nc.data());
+        if (nn < 0) {
+            rc = nn;
+        } else {
+            sc_selfplay_stats st{};
+            rc = sc_selfplay_get_stats(sp, &st);
+            if (!rc && st.error_flags) rc = fail("search error flags set (non-finite PUCT value or pool overflow)", -4);
+            if (root_q) *root_q = nn > 0 ? q[0] : 0.f;
+            n_children = nn > 0 && fc[0] == 1 ? nc[0] : 0;   // the root's children are nodes 1..nc
+            for (int i = 0; i < n_children && i < cap; i++) {
+                if (child_move) child_move[i] = mv[(size_t)1 + i];
+                if (child_n) child_n[i] = n[(size_t)1 + i];
+                if (child_q) child_q[i] = q[(size_t)1 + i];
+                if (child_prior) child_prior[i] = pr[(size_t)1 + i];
+            }
+        }
+    }
+    sc_selfplay_destroy(sp);
+    return rc ? rc : n_children;
+}
+
 int sc_move_uci(uint16_t move, char* buf8) { return sctrace::move_uci(move, buf8); }
 
 /* developer aid (not in the public header): cycle stamps of the last k_mcts launch, out[n_slots][8] */

@@ -62,6 +62,7 @@ ABI = {
     "sc_selfplay_enqueue_interleaved": (_i, [_vp, _i, _i]),
     "sc_selfplay_run": (_i, [_vp, _i64]),
     "sc_selfplay_get_stats": (_i, [_vp, C.POINTER(Stats)]),
+    "sc_search": (_i, [_vp, _vp, _i, _i, _f, _i, C.c_uint64, _i, _vp, _vp, _vp, _vp, _vp]),
     "sc_selfplay_set_search": (_i, [_vp, _f, _f, _i]),
     "sc_selfplay_set_players": (_i, [_vp, _vp, _vp, C.c_uint64, C.c_uint64]),
     "sc_selfplay_enable_timing": (_i, [_vp, _i]),
@@ -336,6 +337,19 @@ class Play:
         """chess_play_encode -> (boards int8[8,8,112], meta int32[7])"""
         e = encode_positions([self.moves], engine=self.engine)
         return e["boards"][0], e["meta"][0]
+
+
+def search(engine, moves, rollout, cpuct=2.5, noise=False, seed=0):
+    """sc_search: one search from the position after `moves` -> (root_q, [(uci, N, Q, prior), ...])"""
+    mv = np.asarray([uci_move(m) if isinstance(m, str) else int(m) for m in moves] or [0], np.uint16)
+    cm, cn = np.zeros(MAX_MOVES, np.uint16), np.zeros(MAX_MOVES, np.int32)
+    cq, cp = np.zeros(MAX_MOVES, np.float32), np.zeros(MAX_MOVES, np.float32)
+    rq = C.c_float(0)
+    n = lib().sc_search(engine.h, _p(mv), len(moves), rollout, cpuct, int(bool(noise)), seed, MAX_MOVES, _p(cm), _p(cn), _p(cq), _p(cp),
+                        C.byref(rq))
+    if n < 0:
+        _check(n)
+    return rq.value, [(move_uci(cm[i]), int(cn[i]), float(cq[i]), float(cp[i])) for i in range(n)]
 
 
 def elo(total, wins, losses):

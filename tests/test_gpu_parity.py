@@ -506,3 +506,19 @@ def test_selfplay_edge_configurations(scamd, C, slots, games, R, steps, temp, ts
         assert all(sum(c[1] for c in s[2]) == R - 1 for s in t["steps"])
     sp.close()
     eng.close()
+
+
+@pytest.mark.gpu
+def test_single_call_search(scamd, orc):
+    """sc_search (NNPlayer::bestmove's search as one call) == the same search on an interactive handle"""
+    eng = scamd.Engine(2, 128, seed=6)
+    line = ["d2d4", "g8f6", "c2c4"]
+    rq, ch = scamd.search(eng, line, 40, cpuct=1.5)
+    pl = scamd.Play(eng, initial_moves=line)
+    pl.mcts(40, cpuct=1.5)
+    _, _, q, ref = pl.inspect()
+    assert rq == q and [(c[0], c[1], c[2]) for c in ch] == ref
+    assert [c[0] for c in ch] == _pushed(orc, line).legal_uci() and sum(c[1] for c in ch) == 39
+    assert abs(sum(c[3] for c in ch) - 1.0) < 0.1
+    pl.close()
+    eng.close()
