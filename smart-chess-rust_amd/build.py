@@ -2,7 +2,8 @@
 
   lib/libsc_engine.so      HIP kernels + C ABI (include/sc_engine.h)          hipcc --offload-arch=gfx950
   lib/libsc_rules_host.so  host build of the device rules code for CPU tests   g++
-  lib/sc-selfplay          CLI mirroring the reference's `selfplay` flags      hipcc
+  lib/sc-selfplay          CLI mirroring the reference's `selfplay` flags      g++
+  lib/sc-play              CLI mirroring the reference's `play` flags (matches) g++
 """
 import os
 import subprocess
@@ -57,6 +58,11 @@ def build(force=False, verbose=False):
     cli = os.path.join(LIB, "sc-selfplay")
     if os.path.exists(cli_src) and (force or _newer(cli, [cli_src, so] + hdrs)):
         _run(["g++", "-O2", "-std=c++17", "-pthread", cli_src, "-o", cli, "-L" + LIB, "-lsc_engine", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath-link,/opt/rocm/lib",
+              "-Wl,-rpath,/opt/rocm/lib"])
+    play_src = os.path.join(CSRC, "play_main.cpp")
+    play = os.path.join(LIB, "sc-play")
+    if os.path.exists(play_src) and (force or _newer(play, [play_src, so] + hdrs)):
+        _run(["g++", "-O2", "-std=c++17", play_src, "-o", play, "-L" + LIB, "-lsc_engine", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath-link,/opt/rocm/lib",
               "-Wl,-rpath,/opt/rocm/lib"])
     return so
 

@@ -57,3 +57,35 @@ def test_cli_groups_write_the_same_games(tmp_path):
     assert r1.returncode == 0 and r2.returncode == 0, (r1.stderr, r2.stderr)
     for k in range(1, 9):
         assert open(str(a / f"trace{k}.json")).read() == open(str(b / f"trace{k}.json")).read(), k
+
+
+PLAY = os.path.join(ROOT, "smart-chess-rust_amd", "lib", "sc-play")
+
+
+def test_play_cli_argument_checks():
+    assert os.path.exists(PLAY)
+    r = subprocess.run([PLAY, "--white-device", "cuda", "-w", "x.scw"], capture_output=True, text=True)   # default opponent: Stockfish
+    assert r.returncode == 2 and "Stockfish" in r.stderr
+    r = subprocess.run([PLAY, "-w", "x.scw"], capture_output=True, text=True)
+    assert r.returncode == 2 and "white-device" in r.stderr
+
+
+@pytest.mark.gpu
+def test_play_cli_writes_match_traces(tmp_path, orc):
+    """`play` flags (src/play.rs:36-84; scripts/leader-board:9-14): two random networks, 6 games, traces with outcome"""
+    pat = str(tmp_path / "w_{}.json")
+    r = subprocess.run([PLAY, "--white-device", "cuda", "--black-device", "cuda", "--black-type", "nn", "--rollout=12",
+                        "--temperature", "0", "--temperature-switch", "0", "--cpuct", "1.5", "-o", pat, "--games", "6",
+                        "--blocks", "1", "--channels", "128", "--white-seed", "3", "--black-seed", "4"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "Players loaded." in r.stdout and "elo.py input: 6/" in r.stdout
+    for k in range(1, 7):
+        js = json.load(open(str(tmp_path / f"w_{k}.json")))
+        assert list(js.keys()) == ["outcome", "steps"] and 1 <= len(js["steps"]) <= 200
+        st = orc.State()
+        for mv, q, kids in js["steps"]:
+            assert sorted(c[0] for c in kids) == sorted(st.legal_uci()) and sum(c[1] for c in kids) == 11
+            st.push(mv)
+        assert (js["outcome"] is None) == (st.outcome() is None)
+        if js["outcome"] is not None:
+            assert js["outcome"] == st.outcome()
