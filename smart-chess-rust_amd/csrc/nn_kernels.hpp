@@ -8,20 +8,23 @@
 // Design (MI355X-first, not a port of any library graph):
 //   * ONE workgroup (4 waves, one per SIMD) owns ONE position for the whole tower.  The position's
 //     activation never leaves the CU: a zero-haloed bf16 image [10x10 pixels][C] in LDS feeds the
-//     implicit-GEMM A operand of every 3x3 conv (M = 64 pixels), the fp32 residual stream lives in
-//     registers in MFMA accumulator layout, and LayerNorm / SE / residual / ReLU are epilogues.
+//     implicit-GEMM A operand of every 3x3 conv (M = 64 pixels), the fp32 residual stream is parked
+//     in LDS between blocks, and LayerNorm / SE / residual / ReLU are register epilogues.
 //     No activation is written to HBM between layers; per position the kernel reads 7 KB of input
 //     planes and writes 32 KB (value-head features) + <=19 KB (policy).
 //   * Weights are streamed from L2 / Infinity Cache straight into VGPRs, pre-packed on the host in
 //     v_mfma_f32_16x16x32_bf16 B-fragment order (one contiguous 1 KiB per wave-load), behind a
-//     4-step register prefetch ring.  All 256 workgroups walk the layers roughly in step, so a
-//     layer's 1.18 MB of weights is served from the XCD's L2 after the first toucher.
+//     4-step register prefetch ring that is carried from layer to layer.  All 256 workgroups walk
+//     the layers roughly in step, so a layer's 1.18 MB of weights is served from the XCD's L2 after
+//     the first toucher.  This file's tower (k_tower, pixels on the MFMA row axis) serves the WIDE
+//     trunk; the narrow trunk runs k_tower32 (nn_tower32.hpp), see DESIGN.md 3.2 for the choice.
 //   * The N dimension is split over the 4 waves (64 output channels each for C=256) so every
 //     workgroup holds complete pixel rows: LayerNorm over channels is a 16-lane DPP/shuffle reduce
 //     plus one LDS exchange between the 4 waves.
 //   * Only the value head's Linear(16391->128) is batched ACROSS positions (its weight is 4 MB and
 //     position-specific in K): k_value_fc1 is a split-K MFMA GEMM over the whole batch, reduced in
-//     fixed order by k_value_finish (bitwise reproducible, no float atomics).
+//     fixed order by k_value_finish -- or, in self-play, by the search kernel's fused tail
+//     (bitwise reproducible, no float atomics).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

@@ -12,6 +12,9 @@
 //     cross-lane add (lane ^ 32) and one LDS exchange between the 4 waves; a lane owns 4 ADJACENT channels per
 //     register quad, so activations go to LDS as 8-byte bf16 stores and the fp32 residual as 16-byte stores.
 //     Only the squeeze-excitation average pool reduces across lanes (halving butterfly, once per block).
+//   * Per-channel parameters of a block are fetched cooperatively and staged in LDS (a per-lane fetch costs a full
+//     1 KiB wave-load on the texture path); the fp32 residual stream stays in registers for the narrow trunk; all 9
+//     taps of a conv are unrolled around a 12-slot weight ring that is carried from layer to layer.
 //   * Pixel tiles are chosen for the LDS banks: tile t holds ranks {2t, 2t+4} in ds_read_b128 lane group A and
 //     {2t+1, 2t+5} in group B; with a pixel stride of an odd multiple of 16 B the 16 haloed addresses of every
 //     lane group fall on 16 distinct 16-byte bank slots for every 3x3 tap.
