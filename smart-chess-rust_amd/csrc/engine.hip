@@ -60,6 +60,9 @@ struct sc_engine {
     scnn::bf16_t* d_hval = nullptr;
     float* d_vpart = nullptr;
     float* d_dbg = nullptr;
+    // scratch arena of sc_encode_positions (Level-1 callers encode one position per call: no malloc/free per call)
+    void* d_enc = nullptr;
+    size_t enc_cap = 0;
 };
 
 static void engine_free_scratch(sc_engine* e) {
@@ -68,6 +71,9 @@ static void engine_free_scratch(sc_engine* e) {
     e->d_boards = nullptr; e->d_meta = nullptr; e->d_lidx = nullptr; e->d_nlegal = nullptr; e->d_prior = nullptr;
     e->d_value = nullptr; e->d_logp = nullptr; e->d_hval = nullptr; e->d_vpart = nullptr; e->d_dbg = nullptr;
     e->cap = 0;
+    dfree({e->d_enc});
+    e->d_enc = nullptr;
+    e->enc_cap = 0;
 }
 static int engine_reserve(sc_engine* e, int n) {
     if (n <= e->cap) return 0;
@@ -284,37 +290,59 @@ int sc_encode_positions(sc_engine* e, int device_id, int n, const uint16_t* move
     }
     if (maxlen > 4000) return fail("move list too long");
     int hist_cap = (int)maxlen + 2;
-    uint16_t* d_moves = nullptr;
-    uint32_t* d_off = nullptr;
-    sc::Position* d_hist = nullptr;
-    int8_t* d_boards = nullptr;
-    int32_t *d_meta = nullptr, *d_nl = nullptr, *d_out = nullptr;
-    uint16_t *d_lm = nullptr, *d_li = nullptr;
-    HIPOK(dalloc(&d_moves, total));
-    HIPOK(dalloc(&d_off, (size_t)n + 1));
-    HIPOK(dalloc(&d_hist, (size_t)n * hist_cap));
-    HIPOK(dalloc(&d_boards, (size_t)n * 7168));
-    HIPOK(dalloc(&d_meta, (size_t)n * 7));
-    HIPOK(dalloc(&d_nl, (size_t)n));
-    HIPOK(dalloc(&d_out, (size_t)n * 4));
-    HIPOK(dalloc(&d_lm, (size_t)n * 224));
-    HIPOK(dalloc(&d_li, (size_t)n * 224));
-    if (total) HIPOK(hipMemcpy(d_moves, moves, (size_t)total * 2, hipMemcpyHostToDevice));
-    HIPOK(hipMemcpy(d_off, move_off, ((size_t)n + 1) * 4, hipMemcpyHostToDevice));
-    HIPOK(hipMemset(d_lm, 0, (size_t)n * 224 * 2));
-    HIPOK(hipMemset(d_li, 0, (size_t)n * 224 * 2));
-    scl::encode_positions(n, d_moves, d_off, nullptr, d_hist, hist_cap, d_boards, d_meta, d_lm, d_li, d_nl, d_out, nullptr);
-    HIPOK(hipGetLastError());
-    HIPOK(hipDeviceSynchronize());
-    if (boards) HIPOK(hipMemcpy(boards, d_boards, (size_t)n * 7168, hipMemcpyDeviceToHost));
-    if (meta) HIPOK(hipMemcpy(meta, d_meta, (size_t)n * 7 * 4, hipMemcpyDeviceToHost));
-    if (legal_moves) HIPOK(hipMemcpy(legal_moves, d_lm, (size_t)n * 224 * 2, hipMemcpyDeviceToHost));
-    if (legal_idx) HIPOK(hipMemcpy(legal_idx, d_li, (size_t)n * 224 * 2, hipMemcpyDeviceToHost));
-    if (n_legal) HIPOK(hipMemcpy(n_legal, d_nl, (size_t)n * 4, hipMemcpyDeviceToHost));
-    if (outcome) HIPOK(hipMemcpy(outcome, d_out, (size_t)n * 16, hipMemcpyDeviceToHost));
-    dfree({d_moves, d_off, d_hist, d_boards, d_meta, d_nl, d_out});
-    dfree({d_lm, d_li});
-    return 0;
+    // one arena for all device buffers of the call; with an engine it persists (grown on demand) and the copies run on
+    // the engine's stream behind a single synchronisation
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        size_t o = off;
+        off += (bytes + 255) & ~(size_t)255;
+        return o;
+    };
+    const size_t o_moves = take((size_t)total * 2 + 2), o_off = take(((size_t)n + 1) * 4), o_hist = take((size_t)n * hist_cap * sizeof(sc::Position));
+    const size_t o_boards = take((size_t)n * 7168), o_meta = take((size_t)n * 28), o_nl = take((size_t)n * 4), o_out = take((size_t)n * 16);
+    const size_t o_lm = take((size_t)n * 448), o_li = take((size_t)n * 448);
+    char* base = nullptr;
+    hipStream_t st = e ? e->stream : nullptr;
+    if (e) {
+        if (off > e->enc_cap) {
+            HIPOK(hipStreamSynchronize(e->stream));
+            dfree({e->d_enc});
+            e->d_enc = nullptr;
+            e->enc_cap = 0;
+            HIPOK(hipMalloc(&e->d_enc, off));
+            e->enc_cap = off;
+        }
+        base = static_cast<char*>(e->d_enc);
+    } else {
+        HIPOK(hipMalloc(reinterpret_cast<void**>(&base), off));
+    }
+    uint16_t* d_moves = reinterpret_cast<uint16_t*>(base + o_moves);
+    uint32_t* d_off = reinterpret_cast<uint32_t*>(base + o_off);
+    sc::Position* d_hist = reinterpret_cast<sc::Position*>(base + o_hist);
+    int8_t* d_boards = reinterpret_cast<int8_t*>(base + o_boards);
+    int32_t* d_meta = reinterpret_cast<int32_t*>(base + o_meta);
+    int32_t* d_nl = reinterpret_cast<int32_t*>(base + o_nl);
+    int32_t* d_out = reinterpret_cast<int32_t*>(base + o_out);
+    uint16_t* d_lm = reinterpret_cast<uint16_t*>(base + o_lm);
+    uint16_t* d_li = reinterpret_cast<uint16_t*>(base + o_li);
+    int rc = 0;
+    auto ok = [&](hipError_t err) {
+        if (err != hipSuccess && !rc) rc = fail(hipGetErrorString(err), -2);
+    };
+    if (total) ok(hipMemcpyAsync(d_moves, moves, (size_t)total * 2, hipMemcpyHostToDevice, st));
+    ok(hipMemcpyAsync(d_off, move_off, ((size_t)n + 1) * 4, hipMemcpyHostToDevice, st));
+    ok(hipMemsetAsync(d_lm, 0, (size_t)n * 448 * 2, st));   // d_lm and d_li are adjacent in the arena
+    if (!rc) scl::encode_positions(n, d_moves, d_off, nullptr, d_hist, hist_cap, d_boards, d_meta, d_lm, d_li, d_nl, d_out, st);
+    ok(hipGetLastError());
+    if (boards) ok(hipMemcpyAsync(boards, d_boards, (size_t)n * 7168, hipMemcpyDeviceToHost, st));
+    if (meta) ok(hipMemcpyAsync(meta, d_meta, (size_t)n * 7 * 4, hipMemcpyDeviceToHost, st));
+    if (legal_moves) ok(hipMemcpyAsync(legal_moves, d_lm, (size_t)n * 224 * 2, hipMemcpyDeviceToHost, st));
+    if (legal_idx) ok(hipMemcpyAsync(legal_idx, d_li, (size_t)n * 224 * 2, hipMemcpyDeviceToHost, st));
+    if (n_legal) ok(hipMemcpyAsync(n_legal, d_nl, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+    if (outcome) ok(hipMemcpyAsync(outcome, d_out, (size_t)n * 16, hipMemcpyDeviceToHost, st));
+    ok(hipStreamSynchronize(st));
+    if (!e) dfree({base});
+    return rc;
 }
 
 // libsmartchess.chess_encode_steps (reference src/lib.rs:46-128) for a batch of recorded games; see include/sc_engine.h
