@@ -212,6 +212,10 @@ int sc_trace_write_json(const char* path, const sc_trace_info* info, const uint1
                         const float* child_q, const float* child_uct);
 /* utility: UCI text of a move (src/chess.rs:513-519); returns strlen */
 int sc_move_uci(uint16_t move, char* buf8);
+/* libsmartchess.chess_encode_move(turn, move) (reference src/lib.rs:37-44; src/chess.rs:544-550, queenmoves.rs,
+ * knightmoves.rs, underpromotions.rs): action index in [0, 4672) of `move` for the side to move, -1 if it has none.
+ * Host function, needs no GPU. */
+int sc_move_index(uint16_t move, int white_to_move);
 
 #ifdef __cplusplus
 }

@@ -1031,6 +1031,10 @@ int sc_search(sc_engine* e, const uint16_t* moves, int n_moves, int rollout, flo
 
 int sc_move_uci(uint16_t move, char* buf8) { return sctrace::move_uci(move, buf8); }
 
+// libsmartchess.chess_encode_move(turn, move) (reference src/lib.rs:37-44): the 4672-wide action index of a move for
+// the side to move (Black's moves are rotated first); -1 if the move has no index.  Pure integer host function.
+int sc_move_index(uint16_t move, int white_to_move) { return sc::move_index((sc::move_t)move, white_to_move ? sc::WHITE : sc::BLACK); }
+
 /* developer aid (not in the public header): cycle stamps of the last k_mcts launch, out[n_slots][8] */
 int sc_selfplay_debug_cycles(sc_selfplay* sp, int enable, unsigned long long* out) {
     if (!sp) return fail("null handle");

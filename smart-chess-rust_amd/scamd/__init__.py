@@ -13,7 +13,7 @@ reference's usage:
 There is NO CPU fallback: importing works anywhere (so the C ABI can be checked), but every
 compute entry point raises EngineError when the HIP library or a GPU is missing.
 """
-from .binding import (ChessHip, Engine, EngineError, Play, SelfPlay, encode_positions, encode_steps, encode_steps_batch,  # noqa: F401
+from .binding import (ChessHip, Engine, EngineError, Play, SelfPlay, encode_move, encode_positions, encode_steps, encode_steps_batch,  # noqa: F401
                       enqueue_interleaved, elo, lib, lib_path, play_match, search,
                       move_uci, uci_move, write_trace_json, TERMINATION)
 from . import binding  # noqa: F401

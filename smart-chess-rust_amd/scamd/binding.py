@@ -77,6 +77,7 @@ ABI = {
     "sc_encode_steps": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sc_trace_write_json": (_i, [C.c_char_p, C.POINTER(TraceInfo), _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sc_move_uci": (_i, [C.c_uint16, C.c_char_p]),
+    "sc_move_index": (_i, [C.c_uint16, _i]),
 }
 
 _lib = None
@@ -337,6 +338,11 @@ class Play:
         """chess_play_encode -> (boards int8[8,8,112], meta int32[7])"""
         e = encode_positions([self.moves], engine=self.engine)
         return e["boards"][0], e["meta"][0]
+
+
+def encode_move(turn_white, move):
+    """libsmartchess.chess_encode_move(turn, move) (reference src/lib.rs:37-44); no GPU needed"""
+    return int(lib().sc_move_index(uci_move(move) if isinstance(move, str) else int(move), int(bool(turn_white))))
 
 
 def search(engine, moves, rollout, cpuct=2.5, noise=False, seed=0):

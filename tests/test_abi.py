@@ -83,3 +83,17 @@ def test_trace_json_format(scamd, tmp_path):
 def test_move_uci_roundtrip(scamd):
     for u in ["e2e4", "e1g1", "a7a8q", "h2h1n", "b7a8r", "c2d1b"]:
         assert scamd.move_uci(scamd.uci_move(u)) == u
+
+
+def test_move_index_host_function(orc):
+    """sc_move_index (libsmartchess.chess_encode_move) is a pure host function of the library: checked against the
+    oracle on every legal move of random positions, and against the reference's recorded examples"""
+    import scamd
+    from helpers import random_games
+    assert scamd.encode_move(True, "e2e4") == 877 and scamd.encode_move(True, "g1f3") == 501    # SURVEY 8c
+    n = 0
+    for moves, st in random_games(orc, 60, 80, seed=3):
+        for m in st.legal_moves():
+            assert scamd.encode_move(st.turn, m) == orc.move_index(m, st.turn)
+            n += 1
+    assert n > 1000
