@@ -522,3 +522,45 @@ def test_single_call_search(scamd, orc):
     assert abs(sum(c[3] for c in ch) - 1.0) < 0.1
     pl.close()
     eng.close()
+
+
+@pytest.mark.gpu
+def test_encode_steps_chunking(scamd, orc):
+    """more plies than one launch holds (8192 per chunk): every chunk boundary falls inside a game and the result still
+    equals the oracle (checked on a sample of games); games of very different lengths share the batch"""
+    import random
+    rnd = random.Random(2)
+    base = [g for g, _ in random_games(orc, 30, 150, seed=5) if len(g) >= 40]
+    games = (base * 5)[:110]
+    steps = [_random_steps(orc, g, rnd) for g in games]
+    total = sum(len(s) for s in steps)
+    assert total > 8192
+    r = scamd.encode_steps_batch(steps)
+    assert (r["status"] == 0).all() and r["boards"].shape[0] == total
+    off = r["ply_off"]
+    for gi in (0, len(steps) // 2, len(steps) - 1) + tuple(i for i in range(len(steps)) if off[i] < 8192 <= off[i + 1]):
+        rc, b, m, d, idx = orc.encode_steps(steps[gi], False)
+        a, e = int(off[gi]), int(off[gi + 1])
+        assert rc == 0 and (r["boards"][a:e] == b).all() and (r["meta"][a:e] == m).all()
+        assert (r["dist"][a:e].view(np.uint32) == d.view(np.uint32)).all()
+
+
+@pytest.mark.gpu
+def test_interleaved_groups_equal_single_handle(scamd, orc):
+    """two handles on two HIP streams driven simulation step by simulation step (sc_selfplay_enqueue_interleaved) play
+    exactly the games a single handle plays: a game depends on its id and the seed only"""
+    cfg = dict(rollout_num=16, num_steps=10, cpuct=2.5, temperature=0.0, temperature_switch=3, with_noise=False, seed=13,
+               evaluator="synth")
+    one = scamd.SelfPlay(None, n_slots=8, n_games=8, first_game_id=50, **cfg)
+    one.run()
+    a = scamd.SelfPlay(None, n_slots=4, n_games=4, first_game_id=50, own_stream=True, **cfg)
+    b = scamd.SelfPlay(None, n_slots=4, n_games=4, first_game_id=54, own_stream=True, **cfg)
+    for _ in range(12):
+        scamd.enqueue_interleaved([a, b], 16)
+    ref = {t["game_id"]: t for t in (one.trace(g) for g in range(8))}
+    got = {t["game_id"]: t for h in (a, b) for t in (h.trace(g) for g in range(4))}
+    assert sorted(got) == sorted(ref) == list(range(50, 58))
+    for gid in ref:
+        assert got[gid]["steps"] == ref[gid]["steps"] and got[gid]["outcome"] == ref[gid]["outcome"]
+        assert got[gid]["steps"] == orc.selfplay_game(rollout_num=16, num_steps=10, cpuct=2.5, temperature=0.0, temperature_switch=3,
+                                                      with_noise=False, seed=13, game_id=gid)["steps"]
