@@ -136,6 +136,9 @@ def run_gpu(args, rank, world, local_rank):
         for sp in sps:
             sp.enable_timing(args.timing_stride)
             sp.timing(reset=True)
+        for sp in sps:
+            sp.sync()
+        cuda_sync()
         barrier()
         t0 = time.perf_counter()
         for _ in range(steps):
