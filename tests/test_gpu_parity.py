@@ -83,10 +83,11 @@ def test_network_matches_reference_goldens(scamd, nb):
     eng.close()
 
 
-@pytest.mark.parametrize("C,nb", [(128, 3), (256, 2)])
+@pytest.mark.parametrize("C,nb", [(128, 3), (256, 2), (128, 0), (256, 0), (128, 19)])
 def test_network_matches_bf16_emulating_oracle(scamd, orc, C, nb):
     """tight check (quantisation points identical, only summation order differs); covers the build-defined
-    128-channel variant that has no reference instantiation"""
+    128-channel variant that has no reference instantiation, a tower without residual blocks and the reference's
+    default depth (19 blocks)"""
     g = np.load(os.path.join(GOLD, "nn_ref_b1_c256.npz"))
     eng = scamd.Engine(nb, C, seed=9)
     net = orc.Net(nb, C, seed=9, emulate_bf16=True)
@@ -94,7 +95,7 @@ def test_network_matches_bf16_emulating_oracle(scamd, orc, C, nb):
     lat = eng.debug(g["boards"][:1], g["meta"][:1], 1000)[0]
     for k in range(4):
         ol, ov, olat = net.forward(g["boards"][k], g["meta"][k], latent=True)
-        assert np.abs(logp[k] - ol).max() < 2e-2 and abs(val[k] - ov) < 5e-3
+        assert np.abs(logp[k] - ol).max() < (2e-2 if nb < 10 else 5e-2) and abs(val[k] - ov) < 5e-3
         if k == 0:
             assert np.abs(lat - olat).max() < 5e-2 * max(1.0, np.abs(olat).max())
     eng.close()
