@@ -230,13 +230,13 @@ __device__ __forceinline__ void vec_w_load(VecW<K, NTW>& v, const bf16_t* __rest
 // x: packed bf16 vector in LDS (16-byte aligned): one ds_read_b128 per k-step instead of 8 scalar reads + converts
 template <int K, int NTW>
 __device__ __forceinline__ void vec_mma(const bf16_t* x, const VecW<K, NTW>& v, int lane, f32x4 (&acc)[NTW]) {
-    const int row16 = lane & 15, kq = lane >> 4;
+    const int kq = lane >> 4;
     typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 #pragma unroll
     for (int s = 0; s < K / 32; s++) {
-        u32x4 raw = *reinterpret_cast<const u32x4*>(x + s * 32 + 8 * kq);
-        if (row16 != 0) raw = u32x4{0u, 0u, 0u, 0u};
-        bf16x8 a = __builtin_bit_cast(bf16x8, raw);
+        // all 16 rows of the A tile read the same vector (an LDS broadcast): every output row is the product, row 0 is used
+        const u32x4 raw = *reinterpret_cast<const u32x4*>(x + s * 32 + 8 * kq);
+        const bf16x8 a = __builtin_bit_cast(bf16x8, raw);
 #pragma unroll
         for (int i = 0; i < NTW; i++) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, v.w[s][i], acc[i], 0, 0, 0);
     }

@@ -56,6 +56,22 @@ __device__ inline int gpix2board(int pt, int i) {
     return ((2 * pt + (inA ? 0 : 1) + 4 * (a >> 3)) << 3) | (a & 7);
 }
 
+// Packed fp32 (v_pk_fma_f32 / v_pk_add_f32: two lanes' worth of work per issue slot) and packed bf16 conversion.
+// With one wave per SIMD the epilogues are bound by VALU issue, and the compiler only forms these from explicit
+// 2-vectors (scalar code got v_fma_f32 per element and a shuffle after every v_cvt_pk_bf16_f32).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16pair __attribute__((ext_vector_type(2)));
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+template <typename V>
+__device__ __forceinline__ f32x2 pair(const V& v, int k) { return f32x2{v[k], v[k + 1]}; }
+__device__ __forceinline__ f32x2 splat(float x) { return f32x2{x, x}; }
+__device__ __forceinline__ uint32_t pk_bf16(f32x2 y) { return __builtin_bit_cast(uint32_t, __builtin_convertvector(y, bf16pair)); }
+// ReLU after rounding, on the bf16 pair as two int16 (negative floats are negative integers; -0 becomes +0)
+__device__ __forceinline__ uint32_t pk_bf16_relu(f32x2 y) {
+    s16x2 s = __builtin_bit_cast(s16x2, __builtin_convertvector(y, bf16pair));
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(s, s16x2{0, 0}));
+}
+
 // first channel of register quad g (registers 4g..4g+3) of channel tile ct
 template <int CT>
 __device__ __forceinline__ int chan32(int wave, int ct, int g, int h) { return wave * (32 * CT) + ct * 32 + 8 * g + 4 * h; }
@@ -203,15 +219,16 @@ __device__ inline void ln_reduce(const f32x16 (&acc)[CT][2], LnStat& L, int coun
     float s[2], q[2];
 #pragma unroll
     for (int pt = 0; pt < 2; pt++) {
-        float a = 0.f, b = 0.f;
+        f32x2 a2 = {0.f, 0.f}, b2 = {0.f, 0.f};
 #pragma unroll
         for (int ct = 0; ct < CT; ct++)
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                float v = acc[ct][pt][r];
-                a += v;
-                b += v * v;
+            for (int r = 0; r < 16; r += 2) {
+                const f32x2 v = pair(acc[ct][pt], r);
+                a2 += v;
+                b2 = v * v + b2;
             }
+        const float a = a2.x + a2.y, b = b2.x + b2.y;
         s[pt] = a + __shfl_xor(a, 32, 64);
         q[pt] = b + __shfl_xor(b, 32, 64);
     }
@@ -244,10 +261,30 @@ __device__ __forceinline__ void ln_apply(f32x16 (&acc)[CT][2], const LnStat& L, 
 #pragma unroll
         for (int ct = 0; ct < CT; ct++)
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                float t = acc[ct][pt][r] * L.rstd[pt] + L.nm[pt];
-                float y = t * G.v[ct][r >> 2][r & 3] + E.v[ct][r >> 2][r & 3];
-                acc[ct][pt][r] = relu ? fmaxf(y, 0.f) : y;
+            for (int r = 0; r < 16; r += 2) {
+                const f32x2 t = pair(acc[ct][pt], r) * splat(L.rstd[pt]) + splat(L.nm[pt]);
+                const f32x2 y = t * pair(G.v[ct][r >> 2], r & 3) + pair(E.v[ct][r >> 2], r & 3);
+                acc[ct][pt][r] = relu ? fmaxf(y.x, 0.f) : y.x;
+                acc[ct][pt][r + 1] = relu ? fmaxf(y.y, 0.f) : y.y;
+            }
+}
+// LayerNorm scale/shift + ReLU straight into the bf16 image (the fp32 values are not needed again)
+template <int CT>
+__device__ __forceinline__ void ln_apply_relu_store(const f32x16 (&acc)[CT][2], const LnStat& L, const ChP<CT>& G, const ChP<CT>& E,
+                                                    const int (&pixbase)[2], int wave, int h) {
+#pragma unroll
+    for (int ct = 0; ct < CT; ct++)
+#pragma unroll
+        for (int pt = 0; pt < 2; pt++)
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                uint32_t w[2];
+#pragma unroll
+                for (int hf = 0; hf < 2; hf++) {
+                    const f32x2 t = pair(acc[ct][pt], 4 * g + 2 * hf) * splat(L.rstd[pt]) + splat(L.nm[pt]);
+                    w[hf] = pk_bf16_relu(t * pair(G.v[ct][g], 2 * hf) + pair(E.v[ct][g], 2 * hf));
+                }
+                *reinterpret_cast<uint2*>(g_smem + pixbase[pt] + chan32<CT>(wave, ct, g, h) * 2) = make_uint2(w[0], w[1]);
             }
 }
 // parameters already in registers (stem, heads)
@@ -269,10 +306,8 @@ __device__ inline void store_image32(const f32x16 (&acc)[CT][2], const int (&pix
         for (int pt = 0; pt < 2; pt++)
 #pragma unroll
             for (int g = 0; g < 4; g++) {
-                uint2 v;
-                v.x = (uint32_t)f2bf(acc[ct][pt][4 * g]) | ((uint32_t)f2bf(acc[ct][pt][4 * g + 1]) << 16);
-                v.y = (uint32_t)f2bf(acc[ct][pt][4 * g + 2]) | ((uint32_t)f2bf(acc[ct][pt][4 * g + 3]) << 16);
-                *reinterpret_cast<uint2*>(g_smem + pixbase[pt] + chan32<CT>(wave, ct, g, h) * 2) = v;
+                *reinterpret_cast<uint2*>(g_smem + pixbase[pt] + chan32<CT>(wave, ct, g, h) * 2) =
+                    make_uint2(pk_bf16(pair(acc[ct][pt], 4 * g)), pk_bf16(pair(acc[ct][pt], 4 * g + 2)));
             }
 }
 
@@ -362,6 +397,11 @@ __global__ __launch_bounds__(256, SC_T32_OCC) void k_tower32(TowerArgs A) {
     const int pixbase[2] = {hidx(bp[0]) * CP * 2, hidx(bp[1]) * CP * 2};   // their rows in the haloed image (bytes)
     const int px[2] = {pixbase[0] + h * 16, pixbase[1] + h * 16};          // + this lane's k half
 
+    // the stem's bias is requested before anything else (its L2 round trip overlaps the input planes' trip from HBM)
+    bf16x8 ring[RS][CT];   // weight prefetch ring, carried from layer to layer
+    ChP<CT> Bn;            // bias of the NEXT conv (requested one epilogue early)
+    ch_load<CT>(Bn, net.wf + net.f_stem, wave, h);
+    __builtin_amdgcn_sched_barrier(0);
     // ---- zero the image (halo stays zero for the whole kernel), then load the 112 input planes
     {
         uint4* z = reinterpret_cast<uint4*>(Xa);
@@ -431,12 +471,9 @@ __global__ __launch_bounds__(256, SC_T32_OCC) void k_tower32(TowerArgs A) {
     for (int k = 0; k < 24; k++) stampv.t[k] = 0;
     stampv.start();
 #endif
-    bf16x8 ring[RS][CT];   // weight prefetch ring, carried from layer to layer
-    ChP<CT> Bn;            // bias of the NEXT conv (requested one epilogue early)
     // ---- conv_block (py/module.py:120-126): conv3x3 112->C (K padded to 128/tap), LN, ReLU
     {
         const float* f = net.wf + net.f_stem;
-        ch_load<CT>(Bn, f, wave, h);
         acc_init<CT>(acc, Bn);
         const bf16_t* w0 = net.wb + net.o_stem;
         conv_mma32<128, 9, CT, TILES, CP, RS, TPI, false>(0, w0, wave, lane, px, acc, ring, (int)((net.wb + net.o_blocks) - w0) * 2);
@@ -453,6 +490,7 @@ __global__ __launch_bounds__(256, SC_T32_OCC) void k_tower32(TowerArgs A) {
     SC_MARK(14);
     dump(0);
 
+    bf16x8 hr[4][2];      // weight ring of the 256-wide head convs
     // ---- residual tower (ResBlockSE.forward, py/module.py:38-46)
 #pragma unroll 1
     for (int b = 0; b < net.n_blocks; b++) {
@@ -489,10 +527,9 @@ __global__ __launch_bounds__(256, SC_T32_OCC) void k_tower32(TowerArgs A) {
             ChP<CT> G, E;
             ch_load_lds<CT>(G, P_G1, wave, h);
             ch_load_lds<CT>(E, P_E1, wave, h);
-            ln_apply<CT>(acc, L, G, E, true);
+            SC_MARK(3);
+            ln_apply_relu_store<CT>(acc, L, G, E, pixbase, wave, h);
         }
-        SC_MARK(3);
-        store_image32<CT>(acc, pixbase, wave, h);
         ch_load_lds<CT>(Bn, P_B2, wave, h);
         __syncthreads();
         SC_MARK(4);
@@ -504,8 +541,9 @@ __global__ __launch_bounds__(256, SC_T32_OCC) void k_tower32(TowerArgs A) {
             conv_mma32<C, 9, CT, TILES, CP, RS, TPI, true>(0, wb + (size_t)9 * C * C, wave, lane, px, acc, ring, nxt);
         }
         SC_MARK(5);
-        // squeeze-excitation weights are requested now: their L2 round trip hides under the LayerNorm.  The columns
-        // of both layers are split over the 4 waves.
+        // squeeze-excitation weights are requested now: their L2 round trip hides under the LayerNorm (issuing them
+        // before conv2 instead measured the same: the conv loop is bound by the same vector-memory path).  The
+        // columns of both layers are split over the 4 waves.
         VecW<C, NTW1> w1;
         VecW<C / 2, NTW> w2;
         vec_w_load<C, NTW1, NT1>(w1, wb + (size_t)18 * C * C, wave * NTW1, lane);
@@ -528,11 +566,22 @@ __global__ __launch_bounds__(256, SC_T32_OCC) void k_tower32(TowerArgs A) {
 #pragma unroll
             for (int ct = 0; ct < CT; ct++)
 #pragma unroll
-                for (int r = 0; r < 16; r++) v[ct * 16 + r] = acc[ct][0][r] + acc[ct][1][r];
+                for (int r = 0; r < 16; r += 2) {
+                    const f32x2 t = pair(acc[ct][0], r) + pair(acc[ct][1], r);
+                    v[ct * 16 + r] = t.x;
+                    v[ct * 16 + r + 1] = t.y;
+                }
             pool_level<NV, NV / 2, 0>(v, lane);
             const int idx = (NV == 32) ? i32 : (i32 >> 1);
             s_xb[chan32<CT>(wave, idx >> 4, (idx & 15) >> 2, h) + (idx & 3)] = f2bf(v[0] * (1.0f / 64.0f));  // conv inputs are bf16 (autocast)
         }
+        // SE biases of this lane's columns (lanes 16..63 mirror lanes 0..15): read before the barrier, off the
+        // fc1 -> fc2 latency chain
+        float sb1[NTW1], sb2[NTW];
+#pragma unroll
+        for (int k = 0; k < NTW1; k++) sb1[k] = *reinterpret_cast<const float*>(g_smem + P_SB1 + (wave * (16 * NTW1) + (lane & 15) * NTW1 + k) * 4);
+#pragma unroll
+        for (int k = 0; k < NTW; k++) sb2[k] = *reinterpret_cast<const float*>(g_smem + P_SB2 + (chan0<NTW>(wave, lane) + k) * 4);
         SC_MARK(9);
         __syncthreads();
         SC_MARK(10);
@@ -548,7 +597,7 @@ __global__ __launch_bounds__(256, SC_T32_OCC) void k_tower32(TowerArgs A) {
                 for (int k = 0; k < NTW1; k++) {
                     // packed column (tile, lane) -> hidden channel ("lane owns NTW1 adjacent channels" order)
                     const int j = wave * (16 * NTW1) + (lane & 15) * NTW1 + k;
-                    float t = hh[k][0] + *reinterpret_cast<const float*>(g_smem + P_SB1 + j * 4);
+                    float t = hh[k][0] + sb1[k];
                     s_hid[j] = f2bf(fmaxf(t, 0.f));
                 }
             }
@@ -565,7 +614,7 @@ __global__ __launch_bounds__(256, SC_T32_OCC) void k_tower32(TowerArgs A) {
                 const int c0 = chan0<NTW>(wave, lane);
 #pragma unroll
                 for (int k = 0; k < NTW; k++)
-                    s_scl[c0 + k] = 1.0f / (1.0f + __expf(-(sc[k][0] + *reinterpret_cast<const float*>(g_smem + P_SB2 + (c0 + k) * 4))));
+                    s_scl[c0 + k] = __frcp_rn(1.0f + __expf(-(sc[k][0] + sb2[k])));
             }
         }
         SC_MARK(11);
@@ -583,9 +632,10 @@ __global__ __launch_bounds__(256, SC_T32_OCC) void k_tower32(TowerArgs A) {
                     else
                         rv = *reinterpret_cast<const f32x4*>(Rs + (pt * 32 + i32) * RP + ch);
 #pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        float y = acc[ct][pt][4 * g + k] * sv[k] + rv[k];
-                        acc[ct][pt][4 * g + k] = fmaxf(y, 0.f);
+                    for (int k = 0; k < 4; k += 2) {
+                        const f32x2 y = pair(acc[ct][pt], 4 * g + k) * pair(sv, k) + pair(rv, k);
+                        acc[ct][pt][4 * g + k] = fmaxf(y.x, 0.f);
+                        acc[ct][pt][4 * g + k + 1] = fmaxf(y.y, 0.f);
                     }
                 }
             }
@@ -613,7 +663,6 @@ __global__ __launch_bounds__(256, SC_T32_OCC) void k_tower32(TowerArgs A) {
     for (int k = 0; k < 2; k++)
         if (tid + 256 * k < 480) hpv[k] = *reinterpret_cast<const f32x4*>(net.wf + net.f_vhead + (size_t)(tid + 256 * k) * 4);
     __builtin_amdgcn_sched_barrier(0);
-    bf16x8 hr[4][2];      // weight ring of the 256-wide head convs
     bf16x8 hr2[4][1];     // ... of the 73-wide one
     // ---- value head conv (py/module.py:89-94): conv1x1 C->256, LN, ReLU -> bf16 features in HBM
     {
@@ -625,6 +674,7 @@ __global__ __launch_bounds__(256, SC_T32_OCC) void k_tower32(TowerArgs A) {
 #pragma unroll
                 for (int r = 0; r < 16; r++) hv[ct][pt][r] = 0.f;
         conv_mma32<C, 1, 2, 8, CP, 4, 1, false>(0, net.wb + net.o_vconv, wave, lane, px, hv, hr, 0);
+        SC_MARK(20);
 #pragma unroll
         for (int k = 0; k < 2; k++)
             if (tid + 256 * k < 480) *reinterpret_cast<f32x4*>(g_smem + HPAR + (tid + 256 * k) * 16) = hpv[k];
@@ -640,21 +690,24 @@ __global__ __launch_bounds__(256, SC_T32_OCC) void k_tower32(TowerArgs A) {
 #pragma unroll
                 for (int r = 0; r < 16; r++) hv[ct][pt][r] += Bv.v[ct][r >> 2][r & 3];
         LnStat L;
-        ln_reduce<2>(hv, L, HEAD, wave, lane, s_stat, ln_parity, bad SC_STAMP_PASS(-2));
+        ln_reduce<2>(hv, L, HEAD, wave, lane, s_stat, ln_parity, bad SC_STAMP_PASS(21));
         ch_load_lds<2>(G, HP_V + HEAD * 4, wave, h);
         ch_load_lds<2>(E, HP_V + 2 * HEAD * 4, wave, h);
         ln_apply<2>(hv, L, G, E, true);
+        SC_MARK(23);
+        // Feature order in HBM = accumulator order ([wave][ct][pt][lane][16 registers], weights.hpp packs the rows of
+        // value_head.ffn.0 to match): a lane's 16 values are 32 contiguous bytes and a wave's two stores fill whole
+        // cache lines.  Writing [pixel][channel] rows from this layout (8 bytes per lane, 512 B apart) cost 4.6 k cycles.
 #pragma unroll
         for (int ct = 0; ct < 2; ct++)
 #pragma unroll
-            for (int pt = 0; pt < 2; pt++)
+            for (int pt = 0; pt < 2; pt++) {
+                bf16_t* dst = A.hval + (size_t)pos * (64 * HEAD) + (size_t)(((wave * 2 + ct) * 2 + pt) * 64 + lane) * 16;
 #pragma unroll
-                for (int g = 0; g < 4; g++) {
-                    uint2 v;
-                    v.x = (uint32_t)f2bf(hv[ct][pt][4 * g]) | ((uint32_t)f2bf(hv[ct][pt][4 * g + 1]) << 16);
-                    v.y = (uint32_t)f2bf(hv[ct][pt][4 * g + 2]) | ((uint32_t)f2bf(hv[ct][pt][4 * g + 3]) << 16);
-                    *reinterpret_cast<uint2*>(A.hval + ((size_t)pos * 64 + bp[pt]) * HEAD + chan32<2>(wave, ct, g, h)) = v;
-                }
+                for (int q = 0; q < 2; q++)
+                    *reinterpret_cast<uint4*>(dst + 8 * q) = make_uint4(pk_bf16(pair(hv[ct][pt], 8 * q)), pk_bf16(pair(hv[ct][pt], 8 * q + 2)),
+                                                                       pk_bf16(pair(hv[ct][pt], 8 * q + 4)), pk_bf16(pair(hv[ct][pt], 8 * q + 6)));
+            }
     }
     SC_MARK(16);
     // ---- policy head (py/module.py:70-76): conv1x1 C->256, LN, conv1x1 256->73, LN (no ReLU between)

@@ -149,6 +149,13 @@ inline void pack_B(uint16_t* out, int K, int NT_TOTAL, int NTW, F getB) {
 
 // W[k][n] accessor -> packed [K/16][TILES][64][8]: v_mfma_f32_32x32x16_bf16 A-fragment order for the transposed
 // (channels on rows) tower, natural channel order (nn_tower32.hpp)
+// host copy of nn_tower32.hpp:gpix2board (GEMM pixel (tile pt, lane-in-tile i) -> board pixel); the value-parity
+// tests fail if the two ever disagree
+inline int gpix2board32(int pt, int i) {
+    const bool inA = (i < 4) || (i >= 12 && i < 16) || (i >= 20 && i < 28);
+    const int a = inA ? (i < 4 ? i : (i < 16 ? i - 8 : i - 12)) : (i < 12 ? i - 4 : (i < 20 ? i - 8 : i - 16));
+    return ((2 * pt + (inA ? 0 : 1) + 4 * (a >> 3)) << 3) | (a & 7);
+}
 template <class F>
 inline void pack_A32(uint16_t* out, int K, int TILES, F getW) {
     const int S = K / 16;
@@ -251,7 +258,13 @@ inline Packed pack(const HostWeights& w, bool v32 = true) {
         }
         const float* F1 = w.t[vt + 4].data();  // [128][16391], column = ch*64 + px
         pack_B(p.wb.data() + L.o_fc1, 64 * H, 8, 2, [&](int k, int n) {
-            int px = k / H, ch = k % H;
+            int px = k / H, ch = k % H;   // k_tower writes the features as [pixel][channel]
+            if (v32) {
+                // k_tower32 writes them in accumulator order: [wave][ct][pt][lane][register] (nn_tower32.hpp, value head)
+                const int r = k & 15, lane = (k >> 4) & 63, pt = (k >> 10) & 1, ct = (k >> 11) & 1, wave = (k >> 12) & 3;
+                ch = wave * 64 + ct * 32 + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3);
+                px = gpix2board32(pt, lane & 31);
+            }
             return F1[(size_t)n * (64 * H + 7) + (size_t)ch * 64 + px];
         });
         for (int j = 0; j < 128; j++) {
