@@ -384,7 +384,7 @@ __global__ __launch_bounds__(256, SC_T32_OCC) void k_tower32(TowerArgs A) {
     constexpr int PAR_OFF = XA_BYTES + RS_BYTES + 4096 + 3072 + 1024 + 64;  // staged per-block parameters, 7.5*C floats
     bf16_t* s_xb = reinterpret_cast<bf16_t*>(s_vec);
     float* s_z = reinterpret_cast<float*>(smem);                            // policy logits [4672], aliases Xa (after the trunk)
-    static_assert(4672 * 4 <= XA_BYTES, "policy logits must fit in the image area");
+    static_assert(4864 * 4 <= XA_BYTES, "policy logits (and the softmax pass that reads 19 x 256 of them) must fit in the image area");
     static_assert(XA_BYTES % 16 == 0 && RS_BYTES % 16 == 0, "LDS regions must stay 16-byte aligned");
 
     const int pos = blockIdx.x;
@@ -397,30 +397,42 @@ __global__ __launch_bounds__(256, SC_T32_OCC) void k_tower32(TowerArgs A) {
     const int pixbase[2] = {hidx(bp[0]) * CP * 2, hidx(bp[1]) * CP * 2};   // their rows in the haloed image (bytes)
     const int px[2] = {pixbase[0] + h * 16, pixbase[1] + h * 16};          // + this lane's k half
 
-    // the stem's bias is requested before anything else (its L2 round trip overlaps the input planes' trip from HBM)
     bf16x8 ring[RS][CT];   // weight prefetch ring, carried from layer to layer
     ChP<CT> Bn;            // bias of the NEXT conv (requested one epilogue early)
-    ch_load<CT>(Bn, net.wf + net.f_stem, wave, h);
+    constexpr int PAR0 = XA_BYTES + RS_BYTES + 4096 + 3072 + 1024 + 64;   // = PAR_OFF below
+    // ---- Every global read of the prologue is issued first: the input planes (7 dwords per thread) and, cooperatively,
+    // the stem's bias / gamma / beta plus block 0's first bias (4*C floats, one 16-byte load per thread, staged in
+    // LDS like the per-block parameters).  Their trip from HBM / L2 overlaps the zero fill instead of following it.
+    const int p_in = tid >> 2, q_in = tid & 3;
+    uint32_t win[7];
+    {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(A.boards + (size_t)pos * 7168 + p_in * 112 + q_in * 28);
+#pragma unroll
+        for (int k = 0; k < 7; k++) win[k] = src[k];
+    }
+    static_assert(C <= 256, "one parameter vector per thread");
+    f32x4 spv = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (tid < 3 * C / 4) spv = *reinterpret_cast<const f32x4*>(net.wf + net.f_stem + tid * 4);
+    else if (tid < C) spv = *reinterpret_cast<const f32x4*>(net.wf + net.f_blocks + (tid - 3 * C / 4) * 4);
     __builtin_amdgcn_sched_barrier(0);
-    // ---- zero the image (halo stays zero for the whole kernel), then load the 112 input planes
+    // ---- zero the image (halo stays zero for the whole kernel), then write the 112 input planes
     {
         uint4* z = reinterpret_cast<uint4*>(Xa);
         for (int k = tid; k < 100 * CP * 2 / 16; k += 256) z[k] = make_uint4(0, 0, 0, 0);
     }
     __syncthreads();
     {
-        const int p = tid >> 2, q = tid & 3;
-        const uint32_t* src = reinterpret_cast<const uint32_t*>(A.boards + (size_t)pos * 7168 + p * 112 + q * 28);
-        uint32_t* dst = reinterpret_cast<uint32_t*>(Xa + hidx(p) * CP + q * 28);   // 56-byte plane groups: 4-byte aligned
+        uint32_t* dst = reinterpret_cast<uint32_t*>(Xa + hidx(p_in) * CP + q_in * 28);   // 56-byte plane groups: 4-byte aligned
 #pragma unroll
         for (int k = 0; k < 7; k++) {
-            uint32_t w = src[k];
+            const uint32_t w = win[k];
             float v[4];
 #pragma unroll
             for (int b = 0; b < 4; b++) v[b] = (float)(int8_t)((w >> (8 * b)) & 0xff);
-            dst[2 * k] = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
-            dst[2 * k + 1] = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+            dst[2 * k] = pk_bf16(f32x2{v[0], v[1]});
+            dst[2 * k + 1] = pk_bf16(f32x2{v[2], v[3]});
         }
+        if (tid < C) *reinterpret_cast<f32x4*>(g_smem + PAR0 + tid * 16) = spv;
     }
     __syncthreads();
 
@@ -473,15 +485,14 @@ __global__ __launch_bounds__(256, SC_T32_OCC) void k_tower32(TowerArgs A) {
 #endif
     // ---- conv_block (py/module.py:120-126): conv3x3 112->C (K padded to 128/tap), LN, ReLU
     {
-        const float* f = net.wf + net.f_stem;
+        ch_load_lds<CT>(Bn, PAR0, wave, h);
         acc_init<CT>(acc, Bn);
         const bf16_t* w0 = net.wb + net.o_stem;
         conv_mma32<128, 9, CT, TILES, CP, RS, TPI, false>(0, w0, wave, lane, px, acc, ring, (int)((net.wb + net.o_blocks) - w0) * 2);
         ChP<CT> G, E;
-        ch_load<CT>(G, f + C, wave, h);
-        ch_load<CT>(E, f + 2 * C, wave, h);
-        ch_load<CT>(Bn, net.wf + net.f_blocks, wave, h);
-        __builtin_amdgcn_sched_barrier(0);
+        ch_load_lds<CT>(G, PAR0 + C * 4, wave, h);
+        ch_load_lds<CT>(E, PAR0 + 2 * C * 4, wave, h);
+        ch_load_lds<CT>(Bn, PAR0 + 3 * C * 4, wave, h);   // read before the barriers that let block 0 restage the area
         layernorm32<CT>(acc, G, E, C, true, wave, lane, s_stat, ln_parity, bad SC_STAMP_PASS(-2));
     }
     store_res();
@@ -504,6 +515,7 @@ __global__ __launch_bounds__(256, SC_T32_OCC) void k_tower32(TowerArgs A) {
         // 1 KiB wave-load through the texture path each, on the critical path of every epilogue.
         constexpr int PAR_V4 = 15 * C / 8;                // float4 count of the window
         constexpr int NPV = (PAR_V4 + 255) / 256;
+        static_assert(PAR0 == PAR_OFF, "prologue staging area");
         constexpr int P_G1 = PAR_OFF, P_E1 = PAR_OFF + 4 * C, P_B2 = PAR_OFF + 8 * C, P_G2 = PAR_OFF + 12 * C, P_E2 = PAR_OFF + 16 * C;
         constexpr int P_SB1 = PAR_OFF + 20 * C, P_SB2 = PAR_OFF + 22 * C, P_BN = PAR_OFF + 26 * C;
 #ifdef SC_EXP
@@ -758,22 +770,36 @@ __global__ __launch_bounds__(256, SC_T32_OCC) void k_tower32(TowerArgs A) {
     __syncthreads();
     SC_MARK(18);
     // ---- log_softmax over 4672 (module.py:80), then the legal-move gather of torch.rs:148-175
-    float mx = -3.0e38f;
-    for (int k = tid; k < 4672; k += 256) mx = fmaxf(mx, s_z[k]);
-    mx = wave_max64(mx);
-    if (lane == 0) s_red[wave] = mx;
+    // One pass over LDS with every read in flight at once (a rolled loop paid the LDS latency 2 x 19 times), and one
+    // barrier: each wave reduces to (max, sum of exp relative to ITS max), the four pairs are combined by everyone.
+    float zv[19];
+#pragma unroll
+    for (int j = 0; j < 19; j++) {
+        const float t = s_z[tid + 256 * j];               // j = 18 reads past 4672 for tid >= 64: still inside the image area
+        zv[j] = (tid + 256 * j < 4672) ? t : -3.0e38f;
+    }
+    float mw = zv[0];
+#pragma unroll
+    for (int j = 1; j < 19; j++) mw = fmaxf(mw, zv[j]);
+    mw = wave_max64(mw);
+    float sw = 0.f;
+#pragma unroll
+    for (int j = 0; j < 19; j++) sw += __expf(zv[j] - mw);
+    sw = wave_sum64(sw);
+    if (lane == 0) {
+        s_red[wave] = mw;
+        s_red[4 + wave] = sw;
+    }
     __syncthreads();
-    mx = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
-    float se = 0.f;
-    for (int k = tid; k < 4672; k += 256) se += __expf(s_z[k] - mx);
-    se = wave_sum64(se);
-    if (lane == 0) s_red[4 + wave] = se;
-    __syncthreads();
-    se = (s_red[4] + s_red[5]) + (s_red[6] + s_red[7]);
+    const float mx = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+    const float se = (s_red[4] * __expf(s_red[0] - mx) + s_red[5] * __expf(s_red[1] - mx)) +
+                     (s_red[6] * __expf(s_red[2] - mx) + s_red[7] * __expf(s_red[3] - mx));
     const float lse = mx + __logf(se);
     if (A.logp) {
         float* lp = A.logp + (size_t)pos * 4672;
-        for (int k = tid; k < 4672; k += 256) lp[k] = s_z[k] - lse;
+#pragma unroll
+        for (int j = 0; j < 19; j++)
+            if (tid + 256 * j < 4672) lp[tid + 256 * j] = zv[j] - lse;
     }
     SC_MARK(19);
     if (A.prior) {
