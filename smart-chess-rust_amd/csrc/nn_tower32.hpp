@@ -228,13 +228,16 @@ __device__ inline void ln_reduce(const f32x16 (&acc)[CT][2], LnStat& L, int coun
                 a2 += v;
                 b2 = v * v + b2;
             }
-        const float a = a2.x + a2.y, b = b2.x + b2.y;
-        s[pt] = a + __shfl_xor(a, 32, 64);
-        q[pt] = b + __shfl_xor(b, 32, 64);
+        s[pt] = a2.x + a2.y;
+        q[pt] = b2.x + b2.y;
     }
-    if (lane < 32) {
-        st[wave * 64 + i] = make_float2(s[0], q[0]);
-        st[wave * 64 + 32 + i] = make_float2(s[1], q[1]);
+    // The two channel halves (lane, lane^32) are added with v_permlane32_swap (gfx950): swapping the upper half of
+    // tile 0's sums with the lower half of tile 1's leaves, after one add, tile 0's pixel sums in lanes 0..31 and
+    // tile 1's in lanes 32..63 -- GEMM pixel = lane, one 8-byte store per lane, no trip through the LDS crossbar.
+    {
+        const auto rs = __builtin_amdgcn_permlane32_swap(__float_as_uint(s[0]), __float_as_uint(s[1]), false, false);
+        const auto rq = __builtin_amdgcn_permlane32_swap(__float_as_uint(q[0]), __float_as_uint(q[1]), false, false);
+        st[wave * 64 + lane] = make_float2(__uint_as_float(rs[0]) + __uint_as_float(rs[1]), __uint_as_float(rq[0]) + __uint_as_float(rq[1]));
     }
     SC_MARK(sk0);
     __syncthreads();
@@ -320,8 +323,7 @@ template <int CTRL>
 __device__ __forceinline__ float dpp_mov(float x) { return dpp_f<CTRL>(x); }
 template <int LVL>
 __device__ __forceinline__ float pool_xchg(float x) {
-    if constexpr (LVL == 0) return __shfl_xor(x, 16, 64);
-    else if constexpr (LVL == 1) return dpp_mov<0x140>(x);   // row_mirror
+    if constexpr (LVL == 1) return dpp_mov<0x140>(x);   // row_mirror
     else if constexpr (LVL == 2) return dpp_mov<0x141>(x);   // row_half_mirror
     else if constexpr (LVL == 3) return dpp_mov<0x4E>(x);    // quad_perm [2,3,0,1]
     else return dpp_mov<0xB1>(x);                            // quad_perm [1,0,3,2]
@@ -330,11 +332,21 @@ template <int NV, int W, int LVL>
 __device__ __forceinline__ void pool_level(float (&v)[NV], int lane) {
     if constexpr (LVL < 5) {
         if constexpr (W >= 1) {
-            const bool hi = (lane & (16 >> LVL)) != 0;
+            if constexpr (LVL == 0) {
+                // lane^16: v_permlane16_swap (gfx950) swaps the odd 16-lane rows of v[t] with the even rows of v[t+W];
+                // the sum of the two results is value t (both lanes' parts) in even rows and value t+W in odd rows
 #pragma unroll
-            for (int t = 0; t < W; t++) {
-                float send = hi ? v[t] : v[t + W], keep = hi ? v[t + W] : v[t];
-                v[t] = keep + pool_xchg<LVL>(send);
+                for (int t = 0; t < W; t++) {
+                    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[t]), __float_as_uint(v[t + W]), false, false);
+                    v[t] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+                }
+            } else {
+                const bool hi = (lane & (16 >> LVL)) != 0;
+#pragma unroll
+                for (int t = 0; t < W; t++) {
+                    float send = hi ? v[t] : v[t + W], keep = hi ? v[t + W] : v[t];
+                    v[t] = keep + pool_xchg<LVL>(send);
+                }
             }
             pool_level<NV, W / 2, LVL + 1>(v, lane);
         } else {
@@ -414,6 +426,7 @@ __global__ __launch_bounds__(256, SC_T32_OCC) void k_tower32(TowerArgs A) {
     f32x4 spv = f32x4{0.f, 0.f, 0.f, 0.f};
     if (tid < 3 * C / 4) spv = *reinterpret_cast<const f32x4*>(net.wf + net.f_stem + tid * 4);
     else if (tid < C) spv = *reinterpret_cast<const f32x4*>(net.wf + net.f_blocks + (tid - 3 * C / 4) * 4);
+    ring_fill<CT, TILES, RS>(ring, net.wb + net.o_stem, wave, lane);   // the stem's first weights too
     __builtin_amdgcn_sched_barrier(0);
     // ---- zero the image (halo stays zero for the whole kernel), then write the 112 input planes
     {
@@ -488,7 +501,7 @@ __global__ __launch_bounds__(256, SC_T32_OCC) void k_tower32(TowerArgs A) {
         ch_load_lds<CT>(Bn, PAR0, wave, h);
         acc_init<CT>(acc, Bn);
         const bf16_t* w0 = net.wb + net.o_stem;
-        conv_mma32<128, 9, CT, TILES, CP, RS, TPI, false>(0, w0, wave, lane, px, acc, ring, (int)((net.wb + net.o_blocks) - w0) * 2);
+        conv_mma32<128, 9, CT, TILES, CP, RS, TPI, true>(0, w0, wave, lane, px, acc, ring, (int)((net.wb + net.o_blocks) - w0) * 2);
         ChP<CT> G, E;
         ch_load_lds<CT>(G, PAR0 + C * 4, wave, h);
         ch_load_lds<CT>(E, PAR0 + 2 * C * 4, wave, h);
@@ -501,7 +514,6 @@ __global__ __launch_bounds__(256, SC_T32_OCC) void k_tower32(TowerArgs A) {
     SC_MARK(14);
     dump(0);
 
-    bf16x8 hr[4][2];      // weight ring of the 256-wide head convs
     // ---- residual tower (ResBlockSE.forward, py/module.py:38-46)
 #pragma unroll 1
     for (int b = 0; b < net.n_blocks; b++) {
@@ -675,6 +687,7 @@ __global__ __launch_bounds__(256, SC_T32_OCC) void k_tower32(TowerArgs A) {
     for (int k = 0; k < 2; k++)
         if (tid + 256 * k < 480) hpv[k] = *reinterpret_cast<const f32x4*>(net.wf + net.f_vhead + (size_t)(tid + 256 * k) * 4);
     __builtin_amdgcn_sched_barrier(0);
+    bf16x8 hr[4][2];      // weight ring of the 256-wide head convs
     bf16x8 hr2[4][1];     // ... of the 73-wide one
     // ---- value head conv (py/module.py:89-94): conv1x1 C->256, LN, ReLU -> bf16 features in HBM
     {
