@@ -273,7 +273,7 @@ def main():
             out["roofline"] = {
                 "bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(tf / PEAK_BF16_TFLOPS, 4), "traffic": load_traffic(m["C"]),
-                "kernel": ("k_tower32" if m['C'] == 128 else "k_tower") + f"<{m['C']}>", "avg_launch_ms": round(m["tower_ms"], 4), "launches_timed": m["tower_launches"],
+                "kernel": f"k_tower32<{m['C']}>", "avg_launch_ms": round(m["tower_ms"], 4), "launches_timed": m["tower_launches"],
                 "flop_per_launch": pos_per_launch * flop_pos, "positions_per_launch": pos_per_launch, "concurrent_groups": m.get("groups", 1),
                 "end_to_end_frac": round(sims / seconds / world * flop_pos / (PEAK_BF16_TFLOPS * 1e12), 4),
             }

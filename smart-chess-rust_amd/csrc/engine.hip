@@ -157,12 +157,11 @@ int sc_engine_create(const sc_net_config* cfg, const char* weights_path, int dev
         if (cfg->n_res_blocks < 0 || cfg->n_res_blocks > 80) return fail("n_res_blocks out of range");
         hw = scw::init_prng(cfg->n_res_blocks, cfg->channels, cfg->seed);
     }
-    // Tower variant, chosen by measured wall time on MI355X: the narrow trunk runs the channel-major
-    // 32x32x16 kernel; the wide trunk is matrix-pipe dense enough that the chip holds a ~13 % lower clock on that
-    // MFMA shape, so it keeps the 16x16x32 kernel.  SC_TOWER_V=1|2 forces one of them (developer switch).
+    // Both trunk widths run the channel-major 32x32x16 tower.  Experiment builds also carry the
+    // pixel-major 16x16x32 kernel; SC_TOWER_V=1 selects it there (developer switch, ignored by the production build).
     const int tv = getenv("SC_TOWER_V") ? atoi(getenv("SC_TOWER_V")) : 0;
-    bool v32 = tv == 2 || (tv != 1 && hw.C == 128);
-    if (!scl::tower_variant_available(hw.C, v32)) v32 = hw.C == 128;   // the forced variant exists in experiment builds only
+    bool v32 = tv != 1;
+    if (!scl::tower_variant_available(hw.C, v32)) v32 = true;
     scw::Packed pk = scw::pack(hw, v32);
     sc_engine* e = new sc_engine();
     e->device = device_id;

@@ -6,6 +6,11 @@
 #define SC_T32_TPI 9   // -4 % cycles, -1 % wall over groups of 3; experiment builds may override)
 #endif
 
+#ifndef SC_T32W_RS
+#define SC_T32W_RS 8    // wide trunk: 8-slot ring, one tap per loop iteration (RS 8/12 x TPI 1/3/9 all measured
+#define SC_T32W_TPI 1   // within 0.5 % of each other)
+#endif
+
 #include <stdlib.h>
 
 #include <algorithm>
@@ -13,32 +18,34 @@
 #include "launchers.hpp"
 
 namespace scl {
-size_t tower16_lds_bytes(int C);
-size_t tower_lds_bytes(int C) {
-    // both tower variants are sized; the larger one is what the callers reserve
-    return std::max<size_t>(tower16_lds_bytes(C), (size_t)scnn::tower32_lds_bytes(C));
-}
 size_t tower16_lds_bytes(int C) {
     size_t cp = (size_t)C + 16, hp = scnn::HEAD + 16, rp = (size_t)C + 4;
     size_t rs = std::max<size_t>(64 * rp * 4, 64 * hp * 2);
     return 100 * cp * 2 + rs + 1024 * 4 + 768 * 4 + 8 * 4 + 4 * 64 * 8;
 }
-// Production build: ONE tower kernel per trunk width (see engine.hip / DESIGN.md 3.2 for how they were chosen).
-// Experiment builds (-DSC_EXP, tools/build_exp.sh) also carry the other variant of each width for A/B runs
-// (SC_TOWER_V=1|2 at engine creation picks the weight packing, and with it the kernel).
+size_t tower_lds_bytes(int C) {
+#ifdef SC_EXP
+    return std::max<size_t>(tower16_lds_bytes(C), (size_t)scnn::tower32_lds_bytes(C));
+#else
+    return (size_t)scnn::tower32_lds_bytes(C);
+#endif
+}
+// Production build: the channel-major tower (nn_tower32.hpp), one instantiation per trunk width.  Experiment builds
+// (-DSC_EXP, tools/build_exp.sh) also carry the pixel-major 16x16x32 kernel (nn_kernels.hpp) of each width for A/B runs
+// (SC_TOWER_V=1 at engine creation picks its weight packing, and with it the kernel).
 const char* nn_init() {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scnn::k_tower<256, 4, 1>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)tower_lds_bytes(256));
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scnn::k_tower32<128, SC_T32_RS, SC_T32_TPI>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, scnn::tower32_lds_bytes(128));
     if (e != hipSuccess) return hipGetErrorString(e);
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scnn::k_tower32<128, SC_T32_RS, SC_T32_TPI>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            scnn::tower32_lds_bytes(128));
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scnn::k_tower32<256, SC_T32W_RS, SC_T32W_TPI>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, scnn::tower32_lds_bytes(256));
     if (e != hipSuccess) return hipGetErrorString(e);
 #ifdef SC_EXP
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scnn::k_tower<128, 12, 3>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)tower_lds_bytes(128));
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scnn::k_tower<256, 4, 1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)tower16_lds_bytes(256));
     if (e != hipSuccess) return hipGetErrorString(e);
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scnn::k_tower32<256, 8, 1>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            scnn::tower32_lds_bytes(256));
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scnn::k_tower<128, 12, 3>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)tower16_lds_bytes(128));
     if (e != hipSuccess) return hipGetErrorString(e);
     if (getenv("SC_EXP_WAND")) {
         int v = (int)strtol(getenv("SC_EXP_WAND"), nullptr, 0);
@@ -53,7 +60,8 @@ bool tower_variant_available(int C, bool tower32) {
     (void)tower32;
     return true;
 #else
-    return tower32 == (C == 128);
+    (void)C;
+    return tower32;
 #endif
 }
 void tower(const scnn::TowerArgs& a, hipStream_t s) {
@@ -61,13 +69,13 @@ void tower(const scnn::TowerArgs& a, hipStream_t s) {
     const scnn::TowerArgs& b = a;
     if (a.net.tower32 && a.net.C == 128)
         hipLaunchKernelGGL((scnn::k_tower32<128, SC_T32_RS, SC_T32_TPI>), dim3(a.n_pos), dim3(256), scnn::tower32_lds_bytes(128), s, b);
-    else if (!a.net.tower32 && a.net.C == 256)
-        hipLaunchKernelGGL((scnn::k_tower<256, 4, 1>), dim3(a.n_pos), dim3(256), tower_lds_bytes(256), s, b);
-#ifdef SC_EXP
     else if (a.net.tower32)
-        hipLaunchKernelGGL((scnn::k_tower32<256, 8, 1>), dim3(a.n_pos), dim3(256), scnn::tower32_lds_bytes(256), s, b);
+        hipLaunchKernelGGL((scnn::k_tower32<256, SC_T32W_RS, SC_T32W_TPI>), dim3(a.n_pos), dim3(256), scnn::tower32_lds_bytes(256), s, b);
+#ifdef SC_EXP
+    else if (a.net.C == 256)
+        hipLaunchKernelGGL((scnn::k_tower<256, 4, 1>), dim3(a.n_pos), dim3(256), tower16_lds_bytes(256), s, b);
     else
-        hipLaunchKernelGGL((scnn::k_tower<128, 12, 3>), dim3(a.n_pos), dim3(256), tower_lds_bytes(128), s, b);
+        hipLaunchKernelGGL((scnn::k_tower<128, 12, 3>), dim3(a.n_pos), dim3(256), tower16_lds_bytes(128), s, b);
 #endif
 }
 void value_fc1(const scnn::Fc1Args& a, hipStream_t s) {

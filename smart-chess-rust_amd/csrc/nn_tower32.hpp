@@ -369,8 +369,7 @@ __device__ __forceinline__ void ring_fill(bf16x8 (&bq)[RS][CT], const bf16_t* __
 
 constexpr int tower32_lds_bytes(int C) {
     const int xa = 100 * (C + 8) * 2;
-    const int r1 = 64 * (C + 4) * 4, r2 = 64 * (HEAD + 8) * 2;
-    return xa + (r1 > r2 ? r1 : r2) + 4096 + 3072 + 1024 + 64 + 15 * C * 2;
+    return xa + 64 * (HEAD + 8) * 2 + 4096 + 3072 + 1024 + 64 + 15 * C * 2;
 }
 
 template <int C, int RS, int TPI>
@@ -382,13 +381,11 @@ __global__ __launch_bounds__(256, SC_T32_OCC) void k_tower32(TowerArgs A) {
     constexpr int TILES = C / 32;
     constexpr int CP = C + 8;          // image pixel stride (elements): (C+8)*2 B is an odd multiple of 16 B
     constexpr int HP = HEAD + 8;
-    constexpr int RP = C + 4;          // residual row stride (floats): odd multiple of 16 B
     constexpr int NTW = C / 64;        // 16-column tiles per wave of the SE layers (16x16x32 vector products)
     constexpr int XA_BYTES = 100 * CP * 2;
-    constexpr int RS_BYTES = (64 * RP * 4 > 64 * HP * 2) ? 64 * RP * 4 : 64 * HP * 2;
+    constexpr int RS_BYTES = 64 * HP * 2;   // the policy head's image
     unsigned char* smem = g_smem;
     bf16_t* Xa = reinterpret_cast<bf16_t*>(smem);                           // [100][CP] bf16 haloed image
-    float* Rs = reinterpret_cast<float*>(smem + XA_BYTES);                  // [64][RP] fp32 residual stream (GEMM pixel order)
     float* s_stat = reinterpret_cast<float*>(smem + XA_BYTES + RS_BYTES);   // 2 x [4][64] float2
     float* s_vec = s_stat + 1024;                                           // SE vectors (packed bf16)
     float* s_scl = s_vec + 768;                                             // [C] SE scales
@@ -452,30 +449,14 @@ __global__ __launch_bounds__(256, SC_T32_OCC) void k_tower32(TowerArgs A) {
     f32x16 acc[CT][2];
     int ln_parity = 0;
     int bad = 0;   // a LayerNorm saw a NaN variance
-    // The fp32 residual stream: in registers for the narrow trunk (16 values per 32-channel tile and pixel tile; the
-    // conv loops leave room), parked in LDS for the wide one (LDS stores run at ~80 B/clk: 32 KB per block there).
-#ifdef SC_EXP_RES_LDS
-    constexpr bool RES_REG = false;
-#else
-    constexpr bool RES_REG = (C == 128);
-#endif
-    f32x16 res[RES_REG ? CT : 1][2];
+    // The fp32 residual stream stays in registers (16 values per 32-channel tile and pixel tile; at C = 256 the
+    // compiler parks part of it in AGPRs): measured faster than a round trip through LDS at both widths.
+    f32x16 res[CT][2];
     auto store_res = [&]() {
-        if constexpr (RES_REG) {
-#pragma unroll
-            for (int ct = 0; ct < CT; ct++)
-#pragma unroll
-                for (int pt = 0; pt < 2; pt++) res[ct][pt] = acc[ct][pt];
-            return;
-        }
 #pragma unroll
         for (int ct = 0; ct < CT; ct++)
 #pragma unroll
-            for (int pt = 0; pt < 2; pt++)
-#pragma unroll
-                for (int g = 0; g < 4; g++)
-                    *reinterpret_cast<f32x4*>(Rs + (pt * 32 + i32) * RP + chan32<CT>(wave, ct, g, h)) =
-                        f32x4{acc[ct][pt][4 * g], acc[ct][pt][4 * g + 1], acc[ct][pt][4 * g + 2], acc[ct][pt][4 * g + 3]};
+            for (int pt = 0; pt < 2; pt++) res[ct][pt] = acc[ct][pt];
     };
     auto dump = [&](int stage) {
         if (A.dbg && A.dbg_stage == stage) {
@@ -650,11 +631,7 @@ __global__ __launch_bounds__(256, SC_T32_OCC) void k_tower32(TowerArgs A) {
                 const f32x4 sv = *reinterpret_cast<const f32x4*>(s_scl + ch);
 #pragma unroll
                 for (int pt = 0; pt < 2; pt++) {
-                    f32x4 rv;
-                    if constexpr (RES_REG)
-                        rv = f32x4{res[ct][pt][4 * g], res[ct][pt][4 * g + 1], res[ct][pt][4 * g + 2], res[ct][pt][4 * g + 3]};
-                    else
-                        rv = *reinterpret_cast<const f32x4*>(Rs + (pt * 32 + i32) * RP + ch);
+                    const f32x4 rv = f32x4{res[ct][pt][4 * g], res[ct][pt][4 * g + 1], res[ct][pt][4 * g + 2], res[ct][pt][4 * g + 3]};
 #pragma unroll
                     for (int k = 0; k < 4; k += 2) {
                         const f32x2 y = pair(acc[ct][pt], 4 * g + k) * pair(sv, k) + pair(rv, k);
@@ -663,7 +640,7 @@ __global__ __launch_bounds__(256, SC_T32_OCC) void k_tower32(TowerArgs A) {
                     }
                 }
             }
-        store_res();                               // each lane rewrites exactly the cells it just read
+        store_res();
         store_image32<CT>(acc, pixbase, wave, h);  // conv2 finished reading Xa before the SE barriers
         ch_load_lds<CT>(Bn, P_BN, wave, h);        // next block's conv1 bias: read before the barrier that frees the staging area
         SC_MARK(12);
@@ -750,7 +727,7 @@ __global__ __launch_bounds__(256, SC_T32_OCC) void k_tower32(TowerArgs A) {
         ch_load_lds<2>(E, HP_P1 + 2 * HEAD * 4, wave, h);
         ln_apply<2>(hp, L, G, E, false);
         const int xb[2] = {XA_BYTES + gpb[0], XA_BYTES + gpb[1]};
-        store_image32<2>(hp, xb, wave, h);   // Xh aliases the residual area (dead after the trunk)
+        store_image32<2>(hp, xb, wave, h);   // Xh: the head image behind Xa
     }
     __syncthreads();
     SC_MARK(17);
