@@ -305,7 +305,7 @@ def load_traffic(C):
     """HBM bytes per tower launch from the rocprofv3 PMC passes committed under profiles/ (null if not collected)"""
     p = os.path.join(ROOT, "profiles", "traffic.json")
     try:
-        return json.load(open(p)).get(f"k_tower<{C}>")
+        return json.load(open(p)).get(f"k_tower32<{C}>")
     except Exception:
         return None
 

@@ -1,6 +1,9 @@
 // nn_kernels.hip -- translation unit of the network kernels.
 #include "nn_kernels.hpp"
 #include "nn_tower32.hpp"
+#ifdef SC_EXP
+#include "nn_tower16.hpp"
+#endif
 #ifndef SC_T32_RS
 #define SC_T32_RS 12   // narrow trunk: 12-slot weight ring, all 9 taps of a conv unrolled (no tap-group loop: measured
 #define SC_T32_TPI 9   // -4 % cycles, -1 % wall over groups of 3; experiment builds may override)

@@ -258,7 +258,7 @@ inline Packed pack(const HostWeights& w, bool v32 = true) {
         }
         const float* F1 = w.t[vt + 4].data();  // [128][16391], column = ch*64 + px
         pack_B(p.wb.data() + L.o_fc1, 64 * H, 8, 2, [&](int k, int n) {
-            int px = k / H, ch = k % H;   // k_tower writes the features as [pixel][channel]
+            int px = k / H, ch = k % H;   // pixel-major kernel (nn_tower16.hpp): features as [pixel][channel]
             if (v32) {
                 // k_tower32 writes them in accumulator order: [wave][ct][pt][lane][register] (nn_tower32.hpp, value head)
                 const int r = k & 15, lane = (k >> 4) & 63, pt = (k >> 10) & 1, ct = (k >> 11) & 1, wave = (k >> 12) & 3;

@@ -1,5 +1,5 @@
 """Copies the rocprofv3 summaries worth judging from gpurun_out/prof_<tag>/ into profiles/ and derives the
-per-launch HBM traffic of the dominant kernel (k_tower) from the PMC passes:
+per-launch HBM traffic of the dominant kernel (k_tower32) from the PMC passes:
 
     bytes = FETCH_SIZE*1024*2 + WRITE_SIZE*1024
 
@@ -52,7 +52,7 @@ def main(tag, ch):
         by = fk[0] * 1024 * 2 + wk[0] * 1024
         rows.append((k, fk[1], fk[0], wk[0], by))
         if "k_tower" in k:
-            traffic[f"k_tower<{ch}>"] = round(by)
+            traffic[f"k_tower32<{ch}>"] = round(by)
     with open(os.path.join(dst, f"{tag}_c{ch}_pmc_hbm.csv"), "w") as f:
         f.write("kernel,launches,avg_FETCH_SIZE_KiB,avg_WRITE_SIZE_KiB,hbm_bytes_per_launch(2*FETCH+WRITE)*1024\n")
         for r in rows:
