@@ -4,17 +4,19 @@
 // changes is the GEMM orientation:   D[channel][pixel] += W^T[channel][k] * X[k][pixel]
 //   * A operand = weights, streamed L2 -> VGPR in 32x32x16 A-fragment order [k16 step][32-channel tile][lane][8]
 //     (natural channel order, 1 KiB per wave-load);  B operand = the LDS image, one ds_read_b128 per 32 pixels.
-//   * A k-step of the narrow trunk is 2 MFMAs of 32 cycles instead of 8 of 16: the same bytes and the same number
-//     of memory instructions ride under half as many, twice as long matrix instructions, so the wave has 24 free
-//     issue cycles per MFMA (8 with 16x16x32) to place its weight loads and LDS reads without stalling the pipe.
+//   * A k-step is 2*CT MFMAs of 32 cycles (CT = C/128 channel tiles per wave): compared with a 16x16x32 tiling the same
+//     bytes and the same number of memory instructions ride under half as many, twice as long matrix instructions, so
+//     the wave has 24 free issue cycles per MFMA (8 with 16x16x32) to place its weight loads and LDS reads.
 //   * Accumulator layout: lane = pixel (lane&31 of a 32-pixel tile), registers = channels
 //     (8*(r>>2) + 4*(lane>>5) + (r&3)).  LayerNorm over channels is therefore an in-register sum plus ONE
-//     cross-lane add (lane ^ 32) and one LDS exchange between the 4 waves; a lane owns 4 ADJACENT channels per
-//     register quad, so activations go to LDS as 8-byte bf16 stores and the fp32 residual as 16-byte stores.
-//     Only the squeeze-excitation average pool reduces across lanes (halving butterfly, once per block).
+//     cross-lane add (lane ^ 32, v_permlane32_swap) and one LDS exchange between the 4 waves; a lane owns 4 ADJACENT
+//     channels per register quad, so activations go to LDS as 8-byte bf16 stores.  Only the squeeze-excitation
+//     average pool reduces across lanes (halving butterfly, once per block).
+//   * Epilogues are VALU-issue-bound at one wave per SIMD: packed fp32 math on register pairs, pair-wise bf16
+//     converts, permlane swaps / DPP instead of LDS-crossbar shuffles (see the helpers below).
 //   * Per-channel parameters of a block are fetched cooperatively and staged in LDS (a per-lane fetch costs a full
-//     1 KiB wave-load on the texture path); the fp32 residual stream stays in registers for the narrow trunk; all 9
-//     taps of a conv are unrolled around a 12-slot weight ring that is carried from layer to layer.
+//     1 KiB wave-load on the texture path); the fp32 residual stream stays in registers; the taps of a conv are
+//     unrolled (all 9 at C = 128) around a weight ring that is carried from layer to layer.
 //   * Pixel tiles are chosen for the LDS banks: tile t holds ranks {2t, 2t+4} in ds_read_b128 lane group A and
 //     {2t+1, 2t+5} in group B; with a pixel stride of an odd multiple of 16 B the 16 haloed addresses of every
 //     lane group fall on 16 distinct 16-byte bank slots for every 3x3 tap.
