@@ -247,7 +247,9 @@ def main():
     if rank == 0:
         flop_pos = 2.0 * macs_per_position(args.blocks, m["C"])
         out = {
-            "metric": "MCTS simulations/sec (whole node), self-play rollout=180",
+            # BASELINE.json's metric string, verbatim, for the configuration it is quoted on
+            "metric": ("MCTS simulations/sec (whole node), self-play rollout=180, at 1/2/4/8 MI355X" if args.rollout == 180
+                       else f"MCTS simulations/sec (whole node), self-play rollout={args.rollout}"),
             "value": round(sims / seconds, 1),
             "unit": "simulations/s",
             "n_gpus": world,

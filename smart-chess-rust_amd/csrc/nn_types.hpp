@@ -29,7 +29,7 @@ struct TowerArgs {
     const int32_t* n_legal;     // [n] or null
     float* prior;               // [n][224] or null
     float* logp;                // [n][4672] or null
-    bf16_t* hval;               // [n][64][256] value-head features (input of k_value_fc1)
+    bf16_t* hval;               // [n][16384] value-head features in the tower's accumulator order (input of k_value_fc1; weights.hpp packs the FC rows to match)
     float* dbg;                 // optional: [n][64][C] residual stream dump
     int dbg_stage;              // -1: none; 0: after stem; b>=1: after block b; 1000: final latent
 };
