@@ -32,7 +32,7 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 struct Stamp {
     bool on;
     long long prev;
-    long long t[24];
+    long long t[40];
     __device__ __forceinline__ void start() { if (on) prev = clock64(); }
     __device__ __forceinline__ void mark(int k) {
         if (on && k >= 0) {
@@ -476,7 +476,7 @@ __global__ __launch_bounds__(256, SC_T32_OCC) void k_tower32(TowerArgs A) {
     Stamp stampv;
     stampv.on = A.dbg && A.dbg_stage == 2000 && lane == 0;
     stampv.prev = 0;
-    for (int k = 0; k < 24; k++) stampv.t[k] = 0;
+    for (int k = 0; k < 40; k++) stampv.t[k] = 0;
     stampv.start();
 #endif
     // ---- conv_block (py/module.py:120-126): conv3x3 112->C (K padded to 128/tap), LN, ReLU
@@ -484,12 +484,15 @@ __global__ __launch_bounds__(256, SC_T32_OCC) void k_tower32(TowerArgs A) {
         ch_load_lds<CT>(Bn, PAR0, wave, h);
         acc_init<CT>(acc, Bn);
         const bf16_t* w0 = net.wb + net.o_stem;
+        SC_MARK(33);
         conv_mma32<128, 9, CT, TILES, CP, RS, TPI, true>(0, w0, wave, lane, px, acc, ring, (int)((net.wb + net.o_blocks) - w0) * 2);
         ChP<CT> G, E;
         ch_load_lds<CT>(G, PAR0 + C * 4, wave, h);
         ch_load_lds<CT>(E, PAR0 + 2 * C * 4, wave, h);
         ch_load_lds<CT>(Bn, PAR0 + 3 * C * 4, wave, h);   // read before the barriers that let block 0 restage the area
-        layernorm32<CT>(acc, G, E, C, true, wave, lane, s_stat, ln_parity, bad SC_STAMP_PASS(-2));
+        SC_MARK(34);
+        layernorm32<CT>(acc, G, E, C, true, wave, lane, s_stat, ln_parity, bad SC_STAMP_PASS(35));
+        SC_MARK(37);
     }
     store_res();
     store_image32<CT>(acc, pixbase, wave, h);  // every wave passed the LN barrier: the input image is dead
@@ -666,8 +669,10 @@ __global__ __launch_bounds__(256, SC_T32_OCC) void k_tower32(TowerArgs A) {
     for (int k = 0; k < 2; k++)
         if (tid + 256 * k < 480) hpv[k] = *reinterpret_cast<const f32x4*>(net.wf + net.f_vhead + (size_t)(tid + 256 * k) * 4);
     __builtin_amdgcn_sched_barrier(0);
-    bf16x8 hr[4][2];      // weight ring of the 256-wide head convs
-    bf16x8 hr2[4][1];     // ... of the 73-wide one
+    // The 1x1 head convs are short (8 or 16 k-steps): their rings hold the WHOLE weight stream of a wave (a 3-step
+    // prefetch distance is 200-400 MFMA cycles, less than the L2 latency: every k-step stalled, 35 % matrix rate).
+    bf16x8 hr[8][2];      // weight ring of the 256-wide head convs (value conv -> policy conv1 carry)
+    bf16x8 hr2[16][1];    // ... of the 73-wide one
     // ---- value head conv (py/module.py:89-94): conv1x1 C->256, LN, ReLU -> bf16 features in HBM
     {
         f32x16 hv[2][2];
@@ -677,12 +682,12 @@ __global__ __launch_bounds__(256, SC_T32_OCC) void k_tower32(TowerArgs A) {
             for (int pt = 0; pt < 2; pt++)
 #pragma unroll
                 for (int r = 0; r < 16; r++) hv[ct][pt][r] = 0.f;
-        conv_mma32<C, 1, 2, 8, CP, 4, 1, false>(0, net.wb + net.o_vconv, wave, lane, px, hv, hr, 0);
+        conv_mma32<C, 1, 2, 8, CP, 8, 1, false>(0, net.wb + net.o_vconv, wave, lane, px, hv, hr,
+                                                (int)((net.wb + net.o_pconv1) - (net.wb + net.o_vconv)) * 2);
         SC_MARK(20);
 #pragma unroll
         for (int k = 0; k < 2; k++)
             if (tid + 256 * k < 480) *reinterpret_cast<f32x4*>(g_smem + HPAR + (tid + 256 * k) * 16) = hpv[k];
-        ring_fill<2, 8, 4>(hr, net.wb + net.o_pconv1, wave, lane);   // policy conv1's first weights: hidden under the LN
         __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
         ChP<2> Bv, G, E;
@@ -720,16 +725,18 @@ __global__ __launch_bounds__(256, SC_T32_OCC) void k_tower32(TowerArgs A) {
         ch_load_lds<2>(Bv, HP_P1, wave, h);
         f32x16 hp[2][2];
         acc_init<2>(hp, Bv);
-        conv_mma32<C, 1, 2, 8, CP, 4, 1, true>(0, net.wb + net.o_pconv1, wave, lane, px, hp, hr, 0);
-        ring_fill<1, 4, 4>(hr2, net.wb + net.o_pconv2, wave, lane);
+        conv_mma32<C, 1, 2, 8, CP, 8, 1, true>(0, net.wb + net.o_pconv1, wave, lane, px, hp, hr, 0);
+        SC_MARK(24);
+        ring_fill<1, 4, 16>(hr2, net.wb + net.o_pconv2, wave, lane);   // hidden under the LayerNorm
         __builtin_amdgcn_sched_barrier(0);
         LnStat L;
-        ln_reduce<2>(hp, L, HEAD, wave, lane, s_stat, ln_parity, bad SC_STAMP_PASS(-2));
+        ln_reduce<2>(hp, L, HEAD, wave, lane, s_stat, ln_parity, bad SC_STAMP_PASS(25));
         ch_load_lds<2>(G, HP_P1 + HEAD * 4, wave, h);
         ch_load_lds<2>(E, HP_P1 + 2 * HEAD * 4, wave, h);
         ln_apply<2>(hp, L, G, E, false);
         const int xb[2] = {XA_BYTES + gpb[0], XA_BYTES + gpb[1]};
         store_image32<2>(hp, xb, wave, h);   // Xh: the head image behind Xa
+        SC_MARK(27);
     }
     __syncthreads();
     SC_MARK(17);
@@ -739,14 +746,17 @@ __global__ __launch_bounds__(256, SC_T32_OCC) void k_tower32(TowerArgs A) {
         f32x16 z[1][2];
         acc_init<1>(z, Bv);
         const int pxh[2] = {gpb[0] + h * 16, gpb[1] + h * 16};
-        conv_mma32<HEAD, 1, 1, 4, HP, 4, 1, true>(XA_BYTES, net.wb + net.o_pconv2, wave, lane, pxh, z, hr2, 0);
+        conv_mma32<HEAD, 1, 1, 4, HP, 16, 1, true>(XA_BYTES, net.wb + net.o_pconv2, wave, lane, pxh, z, hr2, 0);
+        SC_MARK(28);
         // padded channels (>=73) have zero weights, bias, gamma, beta: they add 0 to both LN sums
         LnStat L;
-        ln_reduce<1>(z, L, 73, wave, lane, s_stat, ln_parity, bad SC_STAMP_PASS(-2));
+        ln_reduce<1>(z, L, 73, wave, lane, s_stat, ln_parity, bad SC_STAMP_PASS(29));
         ch_load_lds<1>(G, HP_P2 + POL_PAD * 4, wave, h);
         ch_load_lds<1>(E, HP_P2 + 2 * POL_PAD * 4, wave, h);
         ln_apply<1>(z, L, G, E, false);
+        SC_MARK(31);
         __syncthreads();  // everyone is done with Xa/Xh: the logits may overwrite the image area
+        SC_MARK(32);
 #pragma unroll
         for (int pt = 0; pt < 2; pt++)
 #pragma unroll
@@ -810,7 +820,7 @@ __global__ __launch_bounds__(256, SC_T32_OCC) void k_tower32(TowerArgs A) {
 #ifdef SC_EXP
     SC_MARK(15);
     if (stampv.on)
-        for (int k = 0; k < 24; k++) A.dbg[(size_t)pos * 64 * C + wave * 24 + k] = (float)stampv.t[k];
+        for (int k = 0; k < 40; k++) A.dbg[(size_t)pos * 64 * C + wave * 40 + k] = (float)stampv.t[k];
 #endif
 }
 

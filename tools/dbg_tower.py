@@ -9,12 +9,12 @@ g = np.load(os.path.join(ROOT, "tests", "golden", "nn_ref_b10_c256.npz"))
 boards = np.repeat(g["boards"], 32, axis=0)[:256]
 meta = np.repeat(g["meta"], 32, axis=0)[:256]
 names = ["conv1", "LN1 stats", "LN1 barrier", "LN1 norm", "store+barrier", "conv2", "LN2 stats", "LN2 barrier", "LN2 norm",
-         "pool", "pool barrier", "fc1+fc2", "resid+stores", "end barrier", "prologue+stem", "gather+end", "value head", "policy conv1+LN", "policy conv2+LN+scatter", "softmax", "v: conv", "v: bias+stats", "v: LN barrier", "v: LN apply"]
+         "pool", "pool barrier", "fc1+fc2", "resid+stores", "end barrier", "prologue+stem", "gather+end", "value head", "policy conv1+LN", "policy conv2+LN+scatter", "softmax", "v: conv", "v: bias+stats", "v: LN barrier", "v: LN apply", "p1: conv", "p1: stats", "p1: LN barrier", "p1: apply+store", "p2: conv", "p2: stats", "p2: LN barrier", "p2: apply", "p2: barrier", "stem: prologue", "stem: conv", "stem: stats", "stem: LN barrier", "stem: apply", "-", "-"]
 for C in (128, 256):
     eng = scamd.Engine(10, C, seed=1)
     for _ in range(3):
         d = eng.debug(boards, meta, 2000)
-    t = d[:, 0, :96].astype(np.float64).reshape(-1, 4, 24)[:, :, :24]   # [pos][wave][16]
+    t = d.reshape(d.shape[0], -1)[:, :160].astype(np.float64).reshape(-1, 4, 40)[:, :, :40]   # [pos][wave][16]
     med = np.median(t, axis=0)                                  # [wave][16]
     tot = med[0].sum()
     print(f"C={C}: wave-0 total {tot:.0f} cycles", flush=True)
