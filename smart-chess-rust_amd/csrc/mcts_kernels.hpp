@@ -18,6 +18,7 @@
 // This translation unit is compiled with -ffp-contract=off: the PUCT arithmetic must round
 // exactly like the reference's f32 expression (src/mcts.rs:69-75), which Rust never contracts.
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 
 #include "chess_history.hpp"
@@ -305,102 +306,115 @@ __device__ __forceinline__ void dev_select(const SpParams& p, int g, int lane, i
         const int nc = hdr.nc;
         if (nc == 0) break;
         const int fc = hdr.fc;
-        // children statistics AND their headers in one round trip (lane owns children lane, lane+64, ...)
-        int cn[4];
-        float cw[4], cp[4];
-        NodeHdr ch_[4];
+        // One level of the descent, generic in the number of 64-child rounds it is compiled for: nodes with more than
+        // 64 children are rare (the common case is ONE round), and the 4-round code carries four sets of statistics,
+        // guards and selects through the PUCT arithmetic of every level.
         const int nr = (nc + 63) >> 6;  // rounds of 64 children (wave-uniform): usually 1
+        int best_i = 0;
+        NodeHdr nxt;
+        auto level = [&](auto nrc) {
+            constexpr int NRM = decltype(nrc)::value;
+            // children statistics AND their headers in one round trip (lane owns children lane, lane+64, ...)
+            int cn[NRM];
+            float cw[NRM], cp[NRM];
+            NodeHdr ch_[NRM];
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-            cn[r] = 0;
-            cw[r] = 0.f;
-            cp[r] = 0.f;
-            ch_[r] = NodeHdr{-1, 0, 0};
-            if (r < nr) {
-                int i = lane + 64 * r;
-                bool ok = i < nc;
-                if (r == 0 && depth == 0 && fc == 1) {   // prefetched with the control block
-                    cn[0] = ok ? pf_n : 0;
-                    cw[0] = ok ? pf_w : 0.f;
-                    cp[0] = ok ? pf_p : 0.f;
-                    ch_[0] = ok ? pf_h : NodeHdr{-1, 0, 0};
-                } else {
-                    cn[r] = ok ? N[fc + i] : 0;
-                    cw[r] = ok ? W[fc + i] : 0.f;
-                    cp[r] = ok ? P[fc + i] : 0.f;
-                    ch_[r] = ok ? H[fc + i] : NodeHdr{-1, 0, 0};
+            for (int r = 0; r < NRM; r++) {
+                cn[r] = 0;
+                cw[r] = 0.f;
+                cp[r] = 0.f;
+                ch_[r] = NodeHdr{-1, 0, 0};
+                if (r < nr) {
+                    int i = lane + 64 * r;
+                    bool ok = i < nc;
+                    if (r == 0 && depth == 0 && fc == 1) {   // prefetched with the control block
+                        cn[0] = ok ? pf_n : 0;
+                        cw[0] = ok ? pf_w : 0.f;
+                        cp[0] = ok ? pf_p : 0.f;
+                        ch_[0] = ok ? pf_h : NodeHdr{-1, 0, 0};
+                    } else {
+                        cn[r] = ok ? N[fc + i] : 0;
+                        cw[r] = ok ? W[fc + i] : 0.f;
+                        cp[r] = ok ? P[fc + i] : 0.f;
+                        ch_[r] = ok ? H[fc + i] : NodeHdr{-1, 0, 0};
+                    }
                 }
             }
-        }
-        int best_i = 0;
-        if (nc > 1) {
-            // side to move at `node`: root_turn flipped per depth; reverse_q = Black to move (torch.rs:49-52)
-            const bool reverse_q = ((root_turn ^ (depth & 1)) == BLACK);
-            const bool noisy = depth == 0 && p.with_noise;
-            float* nz = p.noise + (size_t)g * MAXC;
-            float nzv[4] = {0.f, 0.f, 0.f, 0.f};
-            if (noisy) {
-                if (!p.external_noise) {
-                    float gsum = 0.0f;
+            if (nc > 1) {
+                // side to move at `node`: root_turn flipped per depth; reverse_q = Black to move (torch.rs:49-52)
+                const bool reverse_q = ((root_turn ^ (depth & 1)) == BLACK);
+                const bool noisy = depth == 0 && p.with_noise;
+                float* nz = p.noise + (size_t)g * MAXC;
+                float nzv[NRM];
 #pragma unroll
-                    for (int r = 0; r < 4; r++) {
-                        int i = lane + 64 * r;
-                        if (i < nc) {
-                            nzv[r] = gamma03(sc_rng(p.seed, cs.game_id, (uint64_t)root_ply, 3, (uint64_t)cs.sim * 256 + (uint64_t)i));
-                            gsum += nzv[r];
+                for (int r = 0; r < NRM; r++) nzv[r] = 0.f;
+                if (noisy) {
+                    if (!p.external_noise) {
+                        float gsum = 0.0f;
+#pragma unroll
+                        for (int r = 0; r < NRM; r++) {
+                            int i = lane + 64 * r;
+                            if (i < nc) {
+                                nzv[r] = gamma03(sc_rng(p.seed, cs.game_id, (uint64_t)root_ply, 3, (uint64_t)cs.sim * 256 + (uint64_t)i));
+                                gsum += nzv[r];
+                            }
+                        }
+                        gsum = wave_sum_f(gsum);
+#pragma unroll
+                        for (int r = 0; r < NRM; r++) {
+                            int i = lane + 64 * r;
+                            nzv[r] = nzv[r] / gsum;
+                            if (i < nc) nz[i] = nzv[r];
+                        }
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < NRM; r++) {
+                            int i = lane + 64 * r;
+                            if (i < nc) nzv[r] = nz[i];
                         }
                     }
-                    gsum = wave_sum_f(gsum);
+                }
+                int tot = 0;
 #pragma unroll
-                    for (int r = 0; r < 4; r++) {
-                        int i = lane + 64 * r;
-                        nzv[r] = nzv[r] / gsum;
-                        if (i < nc) nz[i] = nzv[r];
-                    }
-                } else {
+                for (int r = 0; r < NRM; r++) tot += cn[r];
+                tot = wave_sum_i(tot);
+                const float sqrt_total = sqrtf((float)tot);
+                float best_u = 0.0f;
+                best_i = -1;
 #pragma unroll
-                    for (int r = 0; r < 4; r++) {
-                        int i = lane + 64 * r;
-                        if (i < nc) nzv[r] = nz[i];
+                for (int r = 0; r < NRM; r++) {
+                    int i = lane + 64 * r;
+                    if (r < nr && i < nc) {
+                        float prior = cp[r];
+                        if (noisy) prior = prior * (1.0f - p.epsilon) + nzv[r] * p.epsilon;  // mcts.rs:181
+                        // uct(): src/mcts.rs:69-75
+                        float average_award = cw[r] / ((float)cn[r] + 1e-4f) * (reverse_q ? -1.0f : 1.0f);
+                        float exploration = (sqrt_total + 0.01f) / (1.0f + (float)cn[r]) * p.cpuct * prior;
+                        float u = average_award + exploration;
+                        U[fc + i] = u;
+                        if (!isfinite(u)) err |= ERR_NONFINITE_UCT;
+                        if (best_i < 0 || u >= best_u) {  // later index wins ties (max_by keeps the last maximum)
+                            best_u = u;
+                            best_i = i;
+                        }
                     }
                 }
+                best_i = wave_argmax_last(best_u, best_i);
             }
-            int tot = 0;
+            best_i = __builtin_amdgcn_readfirstlane(best_i);
+            // header of the chosen child: owned by lane best_i & 63, register best_i >> 6
+            const int rr = best_i >> 6;
+            NodeHdr mine = ch_[0];
 #pragma unroll
-            for (int r = 0; r < 4; r++) tot += cn[r];
-            tot = wave_sum_i(tot);
-            const float sqrt_total = sqrtf((float)tot);
-            float best_u = 0.0f;
-            best_i = -1;
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                int i = lane + 64 * r;
-                if (r < nr && i < nc) {
-                    float prior = cp[r];
-                    if (noisy) prior = prior * (1.0f - p.epsilon) + nzv[r] * p.epsilon;  // mcts.rs:181
-                    // uct(): src/mcts.rs:69-75
-                    float average_award = cw[r] / ((float)cn[r] + 1e-4f) * (reverse_q ? -1.0f : 1.0f);
-                    float exploration = (sqrt_total + 0.01f) / (1.0f + (float)cn[r]) * p.cpuct * prior;
-                    float u = average_award + exploration;
-                    U[fc + i] = u;
-                    if (!isfinite(u)) err |= ERR_NONFINITE_UCT;
-                    if (best_i < 0 || u >= best_u) {  // later index wins ties (max_by keeps the last maximum)
-                        best_u = u;
-                        best_i = i;
-                    }
-                }
-            }
-            best_i = wave_argmax_last(best_u, best_i);
-        }
-        best_i = __builtin_amdgcn_readfirstlane(best_i);
-        // header of the chosen child: owned by lane best_i & 63, register best_i >> 6
-        const int rr = best_i >> 6;
-        NodeHdr mine = rr == 0 ? ch_[0] : rr == 1 ? ch_[1] : rr == 2 ? ch_[2] : ch_[3];
-        NodeHdr nxt;
-        nxt.fc = __builtin_amdgcn_readlane(mine.fc, best_i & 63);
-        int packed = __builtin_amdgcn_readlane((int)mine.nc | ((int)mine.ps << 16), best_i & 63);
-        nxt.nc = (uint16_t)(packed & 0xffff);
-        nxt.ps = (uint16_t)((unsigned)packed >> 16);
+            for (int r = 1; r < NRM; r++)
+                if (rr == r) mine = ch_[r];
+            nxt.fc = __builtin_amdgcn_readlane(mine.fc, best_i & 63);
+            int packed = __builtin_amdgcn_readlane((int)mine.nc | ((int)mine.ps << 16), best_i & 63);
+            nxt.nc = (uint16_t)(packed & 0xffff);
+            nxt.ps = (uint16_t)((unsigned)packed >> 16);
+        };
+        if (nr == 1) level(std::integral_constant<int, 1>{});
+        else level(std::integral_constant<int, 4>{});
         parent_ps = hdr.ps;
         node = fc + best_i;
         hdr = nxt;
@@ -416,6 +430,7 @@ __device__ __forceinline__ void dev_select(const SpParams& p, int g, int lane, i
         }
     }
     SC_STAMP(3);
+    if (p.dbg_cycles && lane == 0) p.dbg_cycles[(size_t)g * 8 + 7] = depth;   // developer stamp: levels walked
     unsigned long long anyerr = __ballot(err != 0);
     if (anyerr) {
         for (int o = 32; o > 0; o >>= 1) err |= __shfl_xor(err, o, 64);

@@ -24,3 +24,10 @@ d = [a[..., 1] - a[..., 0], a[..., 3] - a[..., 2], a[..., 4] - a[..., 3], a[...,
 for n, x in zip(names, d):
     x = x[(x > 0) & (x < 10**7)]
     print(f"{n:24s} median {np.median(x):9.0f}  mean {x.mean():9.0f}  p90 {np.percentile(x, 90):9.0f}  max {x.max():9.0f}  (s_memtime ticks)")
+dep = a[..., 7].astype(np.float64)
+des = (a[..., 3] - a[..., 2]).astype(np.float64)
+ok = (des > 0) & (des < 10**7)
+print(f"levels walked: median {np.median(dep[ok]):.1f} mean {dep[ok].mean():.2f} max {dep[ok].max():.0f}")
+A = np.stack([dep[ok], np.ones(ok.sum())], 1)
+coef = np.linalg.lstsq(A, des[ok], rcond=None)[0]
+print(f"descent ticks ~= {coef[0]:.0f} per level + {coef[1]:.0f}")
