@@ -67,6 +67,37 @@ __device__ __forceinline__ int wave_argmax_last(float u, int idx) {
     }
     return bl;
 }
+// Same contract for the common case of ONE candidate per lane whose index is its lane number (nodes with <= 64
+// children): the wave maximum of the keys (4 DPP max steps), then the HIGHEST lane holding it (ballot + find-last-set)
+// -- a third of the instructions of the (key, index) pair reduction above, on every level of every descent.
+__device__ __forceinline__ int wave_argmax_last_lane(float u, bool has) {
+    unsigned b = __builtin_bit_cast(unsigned, u + 0.0f);
+    unsigned key = (b & 0x80000000u) ? ~b : (b | 0x80000000u);   // >= 0x00800000 for every finite float
+    int k = has ? (int)key : 0;
+    auto umax = [](int a, int b2) { return (int)((unsigned)a > (unsigned)b2 ? (unsigned)a : (unsigned)b2); };
+    int m = k;
+    m = umax(m, dpp_i<0xB1>(m));
+    m = umax(m, dpp_i<0x4E>(m));
+    m = umax(m, dpp_i<0x141>(m));
+    m = umax(m, dpp_i<0x140>(m));
+    const int wm = umax(umax(__builtin_amdgcn_readlane(m, 0), __builtin_amdgcn_readlane(m, 16)),
+                        umax(__builtin_amdgcn_readlane(m, 32), __builtin_amdgcn_readlane(m, 48)));
+    const unsigned long long mask = __ballot(has && k == wm);
+    return mask ? 63 - __clzll((long long)mask) : -1;
+}
+// float sum over the wave by DPP (row of 16) + readlanes; used where the summation order is free (root noise
+// normalisation) -- wave_sum_f below keeps the xor-butterfly order that k_value_finish shares
+__device__ __forceinline__ float wave_sum_f_dpp(float v) {
+    auto d = [](float x, auto tag) {
+        return __builtin_bit_cast(float, dpp_i<decltype(tag)::value>(__builtin_bit_cast(int, x)));
+    };
+    v += d(v, std::integral_constant<int, 0xB1>{});
+    v += d(v, std::integral_constant<int, 0x4E>{});
+    v += d(v, std::integral_constant<int, 0x141>{});
+    v += d(v, std::integral_constant<int, 0x140>{});
+    auto rl = [&](int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); };
+    return (rl(0) + rl(16)) + (rl(32) + rl(48));
+}
 __device__ inline float wave_sum_f(float v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
@@ -359,7 +390,7 @@ __device__ __forceinline__ void dev_select(const SpParams& p, int g, int lane, i
                                 gsum += nzv[r];
                             }
                         }
-                        gsum = wave_sum_f(gsum);
+                        gsum = wave_sum_f_dpp(gsum);
 #pragma unroll
                         for (int r = 0; r < NRM; r++) {
                             int i = lane + 64 * r;
@@ -399,7 +430,8 @@ __device__ __forceinline__ void dev_select(const SpParams& p, int g, int lane, i
                         }
                     }
                 }
-                best_i = wave_argmax_last(best_u, best_i);
+                if constexpr (NRM == 1) best_i = wave_argmax_last_lane(best_u, best_i >= 0);   // best_i is the lane number here
+                else best_i = wave_argmax_last(best_u, best_i);
             }
             best_i = __builtin_amdgcn_readfirstlane(best_i);
             // header of the chosen child: owned by lane best_i & 63, register best_i >> 6
