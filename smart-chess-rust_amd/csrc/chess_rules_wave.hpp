@@ -15,29 +15,40 @@
 
 namespace sc {
 
-__device__ __forceinline__ bb_t wave_or64(bb_t v) {
-    unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        lo |= (unsigned)__shfl_xor((int)lo, o, 64);
-        hi |= (unsigned)__shfl_xor((int)hi, o, 64);
-    }
-    return ((bb_t)hi << 32) | lo;
+// Cross-lane steps are DPP moves inside each row of 16 lanes plus readlanes between the four rows -- plain VALU /
+// scalar work; the xor / shift shuffles they replace were 6-12 dependent trips through the LDS crossbar per call.
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp_u(unsigned x) {
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, 0xf, 0xf, false);   // lanes without a source read 0
 }
+__device__ __forceinline__ unsigned wave_or32(unsigned v) {
+    v |= dpp_u<0xB1>(v);    // quad_perm [1,0,3,2]
+    v |= dpp_u<0x4E>(v);    // quad_perm [2,3,0,1]
+    v |= dpp_u<0x141>(v);   // row_half_mirror
+    v |= dpp_u<0x140>(v);   // row_mirror: every lane holds its row's OR
+    return (unsigned)(__builtin_amdgcn_readlane((int)v, 0) | __builtin_amdgcn_readlane((int)v, 16) | __builtin_amdgcn_readlane((int)v, 32) |
+                      __builtin_amdgcn_readlane((int)v, 48));
+}
+// OR over the wave; the result is wave-uniform (SGPRs)
+__device__ __forceinline__ bb_t wave_or64(bb_t v) { return ((bb_t)wave_or32((unsigned)(v >> 32)) << 32) | wave_or32((unsigned)v); }
 __device__ __forceinline__ bb_t uniform64(bb_t v) {
     unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
     unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
     return ((bb_t)hi << 32) | lo;
 }
-// sum of x over the lanes ABOVE this one (lane 63 gets 0), and the wave total in `total`
+// sum of x over the lanes ABOVE this one (lane 63 gets 0), and the wave total in `total`: inclusive suffix scan inside
+// each row (row_shl:n -- lane i reads lane i+n of its row, 0 past the row's end), then the totals of the rows above
 __device__ __forceinline__ unsigned wave_suffix_excl(unsigned x, int lane, unsigned& total) {
     unsigned s = x;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        unsigned o = (unsigned)__shfl_down((int)s, d, 64);
-        if (lane + d < 64) s += o;
-    }
-    total = (unsigned)__builtin_amdgcn_readfirstlane((int)s);   // lane 0 holds the sum over all lanes
+    s += dpp_u<0x101>(s);   // row_shl:1
+    s += dpp_u<0x102>(s);   // row_shl:2
+    s += dpp_u<0x104>(s);   // row_shl:4
+    s += dpp_u<0x108>(s);   // row_shl:8
+    const unsigned t0 = (unsigned)__builtin_amdgcn_readlane((int)s, 0), t1 = (unsigned)__builtin_amdgcn_readlane((int)s, 16);
+    const unsigned t2 = (unsigned)__builtin_amdgcn_readlane((int)s, 32), t3 = (unsigned)__builtin_amdgcn_readlane((int)s, 48);
+    const int row = lane >> 4;
+    s += (row < 1 ? t1 : 0u) + (row < 2 ? t2 : 0u) + (row < 3 ? t3 : 0u);
+    total = t0 + t1 + t2 + t3;
     return s - x;
 }
 

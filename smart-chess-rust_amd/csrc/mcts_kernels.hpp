@@ -85,8 +85,8 @@ __device__ __forceinline__ int wave_argmax_last_lane(float u, bool has) {
     const unsigned long long mask = __ballot(has && k == wm);
     return mask ? 63 - __clzll((long long)mask) : -1;
 }
-// float sum over the wave by DPP (row of 16) + readlanes; used where the summation order is free (root noise
-// normalisation) -- wave_sum_f below keeps the xor-butterfly order that k_value_finish shares
+// float sum over the wave by DPP (row of 16) + readlanes, in the order of nn_kernels.hpp's wave_sum64 (the fused value
+// tail below and k_value_finish must agree bitwise)
 __device__ __forceinline__ float wave_sum_f_dpp(float v) {
     auto d = [](float x, auto tag) {
         return __builtin_bit_cast(float, dpp_i<decltype(tag)::value>(__builtin_bit_cast(int, x)));
@@ -699,7 +699,7 @@ __device__ inline float value_from_partials(const SpParams& p, int g, int lane) 
     s0 = s0 > 0.f ? s0 : 0.f;
     s1 = s1 > 0.f ? s1 : 0.f;
     float part = s0 * w2.x + s1 * w2.y;
-    part = wave_sum_f(part);
+    part = wave_sum_f_dpp(part);   // same order as k_value_finish (nn_kernels.hpp: wave_sum64)
     float v = tanhf(part + wf[p.vf_fc2b]);
     return v * (float)(meta[0] * 2 - 1);
 }

@@ -212,7 +212,7 @@ __global__ __launch_bounds__(64) void k_value_finish(VfinArgs A) {
     s1 = s1 > 0.f ? s1 : 0.f;
     const float2 w2 = *reinterpret_cast<const float2*>(wf + A.net.f_fc2w + j);
     float part = __fadd_rn(__fmul_rn(s0, w2.x), __fmul_rn(s1, w2.y));
-    for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+    part = wave_sum64(part);   // same DPP order as the fused tail in the search kernel (mcts_kernels.hpp: wave_sum_f_dpp)
     if (lane == 0) {
         float v = tanhf(part + wf[A.net.f_fc2b]);
         A.value[pos] = v * (float)(A.meta[(size_t)pos * A.meta_stride] * 2 - 1);
