@@ -644,64 +644,75 @@ __device__ inline void finish_game(SpParams& p, int g, int lane, int has_outcome
 // src/main.rs:198-233: snapshot root/children into the trace, mcts::step (mcts.rs:292-328), outcome.
 // value head tail for one position (nn_kernels.hpp k_value_finish, fused here so that the search step needs
 // no separate launch): + meta columns + bias, ReLU, Linear 128->1, tanh, times (2*turn-1)
-__device__ inline float value_from_partials(const SpParams& p, int g, int lane) {
+// Two halves: every address depends on the game slot only, so the loads are requested at the very top of the expansion,
+// together with the control block (one round trip earlier than the path statistics, which need the control block).
+struct ValueTail {
+    float2 acc[64];
+    float2 bias, w2, wm[7];
+    int32_t meta[7];
+    float fc2b;
+};
+__device__ __forceinline__ void value_tail_issue(const SpParams& p, int g, int lane, ValueTail& t) {
     const float* wf = p.vf_w;
     const int32_t* meta = p.meta + (size_t)g * 8;
-    float m[7];
 #pragma unroll
-    for (int k = 0; k < 7; k++) {
-        // meta is fed to the net as bf16 (src/backends/torch.rs:120-123)
-        uint32_t u = __builtin_bit_cast(uint32_t, (float)meta[k]);
-        u = (u + 0x7fffu + ((u >> 16) & 1u)) & 0xffff0000u;
-        m[k] = __builtin_bit_cast(float, u);
-    }
+    for (int k = 0; k < 7; k++) t.meta[k] = meta[k];
     // lane owns output columns 2*lane, 2*lane+1; ALL split-K partials are requested before the first add (one L2
     // round trip instead of one per 32 partials), then summed in fixed ascending order (same order and column
     // mapping as k_value_finish: the two paths are bitwise identical)
     const int j = 2 * lane;
-    float2 acc[64];
     const float* vp = p.vpart + (size_t)g * 128 + j;
     const size_t vstride = (size_t)p.n_slots * 128;
     // split-K is 32 or 64 (engine.hip): two unconditional batches -- a per-partial bound check makes the compiler
     // branch around (and wait for) every single load
 #pragma unroll
-    for (int ks = 0; ks < 32; ks++) acc[ks] = *reinterpret_cast<const float2*>(vp + (size_t)ks * vstride);
+    for (int ks = 0; ks < 32; ks++) t.acc[ks] = *reinterpret_cast<const float2*>(vp + (size_t)ks * vstride);
     if (p.vf_ksplit > 32) {
 #pragma unroll
-        for (int ks = 32; ks < 64; ks++) acc[ks] = *reinterpret_cast<const float2*>(vp + (size_t)ks * vstride);
+        for (int ks = 32; ks < 64; ks++) t.acc[ks] = *reinterpret_cast<const float2*>(vp + (size_t)ks * vstride);
     } else {
 #pragma unroll
-        for (int ks = 32; ks < 64; ks++) acc[ks] = make_float2(0.f, 0.f);
+        for (int ks = 32; ks < 64; ks++) t.acc[ks] = make_float2(0.f, 0.f);
     }
-    const float2 bias = *reinterpret_cast<const float2*>(wf + p.vf_fc1b + j);
-    const float2 w2 = *reinterpret_cast<const float2*>(wf + p.vf_fc2w + j);
-    float2 wm[7];
+    t.bias = *reinterpret_cast<const float2*>(wf + p.vf_fc1b + j);
+    t.w2 = *reinterpret_cast<const float2*>(wf + p.vf_fc2w + j);
 #pragma unroll
-    for (int k = 0; k < 7; k++) wm[k] = *reinterpret_cast<const float2*>(wf + p.vf_fc1m + k * 128 + j);
-    float s0 = bias.x, s1 = bias.y;
+    for (int k = 0; k < 7; k++) t.wm[k] = *reinterpret_cast<const float2*>(wf + p.vf_fc1m + k * 128 + j);
+    t.fc2b = wf[p.vf_fc2b];
+}
+__device__ __forceinline__ float value_tail_finish(const SpParams& p, const ValueTail& t) {
+    float m[7];
+#pragma unroll
+    for (int k = 0; k < 7; k++) {
+        // meta is fed to the net as bf16 (src/backends/torch.rs:120-123)
+        uint32_t u = __builtin_bit_cast(uint32_t, (float)t.meta[k]);
+        u = (u + 0x7fffu + ((u >> 16) & 1u)) & 0xffff0000u;
+        m[k] = __builtin_bit_cast(float, u);
+    }
+    float s0 = t.bias.x, s1 = t.bias.y;
 #pragma unroll
     for (int ks = 0; ks < 32; ks++) {
-        s0 += acc[ks].x;
-        s1 += acc[ks].y;
+        s0 += t.acc[ks].x;
+        s1 += t.acc[ks].y;
     }
     if (p.vf_ksplit > 32) {
 #pragma unroll
         for (int ks = 32; ks < 64; ks++) {
-            s0 += acc[ks].x;
-            s1 += acc[ks].y;
+            s0 += t.acc[ks].x;
+            s1 += t.acc[ks].y;
         }
     }
 #pragma unroll
     for (int k = 0; k < 7; k++) {
-        s0 += m[k] * wm[k].x;
-        s1 += m[k] * wm[k].y;
+        s0 += m[k] * t.wm[k].x;
+        s1 += m[k] * t.wm[k].y;
     }
     s0 = s0 > 0.f ? s0 : 0.f;
     s1 = s1 > 0.f ? s1 : 0.f;
-    float part = s0 * w2.x + s1 * w2.y;
+    float part = s0 * t.w2.x + s1 * t.w2.y;
     part = wave_sum_f_dpp(part);   // same order as k_value_finish (nn_kernels.hpp: wave_sum64)
-    float v = tanhf(part + wf[p.vf_fc2b]);
-    return v * (float)(meta[0] * 2 - 1);
+    float v = tanhf(part + t.fc2b);
+    return v * (float)(t.meta[0] * 2 - 1);
 }
 
 // cs_out / cs_valid: the control block as this function leaves it, handed to dev_select in registers (a reload would be
@@ -721,6 +732,8 @@ __device__ __forceinline__ void dev_expand(SpParams& p, int g, int lane, Positio
         lmv[k] = i < MAXC ? p.legal_mv[(size_t)g * MAXC + i] : (uint16_t)0;
     }
     const unsigned long long sc_sims = p.slot_cnt[(size_t)g * 2], sc_evals = p.slot_cnt[(size_t)g * 2 + 1];
+    ValueTail vt;
+    if (p.vf_fused) value_tail_issue(p, g, lane, vt);   // used when the leaf turns out to be a network evaluation
     cs_out = cs;
     cs_valid = true;
     if (cs.status != ST_ACTIVE || cs.leaf_kind == LK_NONE) return;
@@ -750,7 +763,7 @@ __device__ __forceinline__ void dev_expand(SpParams& p, int g, int lane, Positio
         w0 = W[pth];
     }
     if (kind == LK_EVAL) {
-        value = p.vf_fused ? value_from_partials(p, g, lane) : p.value[g];
+        value = p.vf_fused ? value_tail_finish(p, vt) : p.value[g];
         int n = cs.n_legal;
         if (n_nodes + n > p.node_cap || n_exp + 1 >= p.tpos_cap) {
             err = ERR_POOL_OVERFLOW;
