@@ -19,3 +19,7 @@ find $OUT -name "*.csv" | head -20
 # keep the merge small: drop per-dispatch traces, keep stats + counter csv
 find $OUT -name "*kernel_trace.csv" -size +20M -delete || true
 du -sh $OUT
+# MFMA-pipe utilisation of the kernels (SQ + GRBM counters, their own pass)
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_mfma_c$CH -- python3 $R/bench.py --steps 1 --warmup 1 --no-alt --cpu-budget 0 --channels $CH > /dev/null 2> $OUT/pmc_mfma_c$CH.err
+echo "mfma pass done"
+find $OUT -name "*kernel_trace.csv" -size +20M -delete || true
