@@ -299,16 +299,19 @@ __device__ __forceinline__ void dev_select(const SpParams& p, int g, int lane, i
     GameCtl& c = p.ctl[g];
     GameCtl cs = cs_pre;
     if (!cs_pre_valid) cs = uniform(c);  // one 64-byte fetch instead of a chain of dependent field loads
-    // the root position and the root header ride in the same round trip (their addresses depend on g only)
-    const Position root = uniform(p.tpos[(size_t)g * p.tpos_cap]);
-    NodeHdr hdr = uniform(p.H[(size_t)g * p.node_cap]);
-    // ... and so do the root's children: the tree is rebuilt every ply with the root at node 0 and its children at
-    // nodes 1..nc (first expansion), so their statistics can be requested before the header is known
-    const size_t nb0 = (size_t)g * p.node_cap + 1 + lane;
-    const bool pf_ok = 1 + lane < p.node_cap;
-    const int pf_n = pf_ok ? p.N[nb0] : 0;
-    const float pf_w = pf_ok ? p.W[nb0] : 0.f, pf_p = pf_ok ? p.P[nb0] : 0.f;
-    const NodeHdr pf_h = pf_ok ? p.H[nb0] : NodeHdr{-1, 0, 0};
+    // The root position, the root header and the root's children ride in ONE round trip (their addresses depend on g
+    // only: the tree is rebuilt every ply with the root at node 0 and its children at nodes 1..nc, first expansion).
+    // As in dev_expand: all loads first, unguarded (clamped index; lanes past the child count are masked where the
+    // values are used), and the wave-uniform ones move to SGPRs only after the last load has been issued.
+    const Position root_raw = p.tpos[(size_t)g * p.tpos_cap];
+    const NodeHdr hdr_raw = p.H[(size_t)g * p.node_cap];
+    const size_t nb0 = (size_t)g * p.node_cap + (1 + lane < p.node_cap ? 1 + lane : p.node_cap - 1);
+    const int pf_n = p.N[nb0];
+    const float pf_w = p.W[nb0], pf_p = p.P[nb0];
+    const NodeHdr pf_h = p.H[nb0];
+    __builtin_amdgcn_sched_barrier(0);
+    const Position root = uniform(root_raw);
+    NodeHdr hdr = uniform(hdr_raw);
     if (cs.status != ST_ACTIVE) {
         if (lane == 0) c.leaf_kind = LK_NONE;
         return;
@@ -720,20 +723,34 @@ __device__ __forceinline__ float value_tail_finish(const SpParams& p, const Valu
 __device__ __forceinline__ void dev_expand(SpParams& p, int g, int lane, Position* s_np_p, GameCtl& cs_out, bool& cs_valid) {
     Position& s_np = *s_np_p;
     GameCtl& c = p.ctl[g];
-    const GameCtl cs = uniform(c);  // one 64-byte fetch instead of a chain of dependent field loads
-    // speculative fetches (addresses depend on g only), in flight together with the control block
-    const int pth = lane < p.max_depth ? p.path[(size_t)g * p.max_depth + lane] : 0;
+    // First round trip: EVERYTHING whose address depends on the game slot only -- the control block (one 64-byte
+    // fetch), the recorded path, the leaf's priors and legal moves, the slot counters, the value partials.  Order
+    // matters: the loads are issued with clamped indices and no guards, and the control block is moved to SGPRs only
+    // AFTER the last of them -- a readfirstlane right behind its load (or a load under `cond ? load : 0`, which becomes
+    // a branch around the load with its own wait) parks the wave for a full round trip before the next load is even
+    // issued: the kernel used to start with three serialised trips (control block, path, the rest).
+    const GameCtl craw = c;
+    const int pth_raw = p.path[(size_t)g * p.max_depth + (lane < p.max_depth ? lane : p.max_depth - 1)];
     float prv[4];
     uint16_t lmv[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        const int i = lane + 64 * k;
-        prv[k] = i < MAXC ? p.prior[(size_t)g * MAXC + i] : 0.f;
-        lmv[k] = i < MAXC ? p.legal_mv[(size_t)g * MAXC + i] : (uint16_t)0;
+        const int i = lane + 64 * k, ic = i < MAXC ? i : MAXC - 1;
+        prv[k] = p.prior[(size_t)g * MAXC + ic];
+        lmv[k] = p.legal_mv[(size_t)g * MAXC + ic];
     }
     const unsigned long long sc_sims = p.slot_cnt[(size_t)g * 2], sc_evals = p.slot_cnt[(size_t)g * 2 + 1];
     ValueTail vt;
     if (p.vf_fused) value_tail_issue(p, g, lane, vt);   // used when the leaf turns out to be a network evaluation
+    __builtin_amdgcn_sched_barrier(0);
+    const GameCtl cs = uniform(craw);
+    const int pth = lane < p.max_depth ? pth_raw : 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int i = lane + 64 * k;
+        prv[k] = i < MAXC ? prv[k] : 0.f;
+        lmv[k] = i < MAXC ? lmv[k] : (uint16_t)0;
+    }
     cs_out = cs;
     cs_valid = true;
     if (cs.status != ST_ACTIVE || cs.leaf_kind == LK_NONE) return;
