@@ -34,6 +34,18 @@ def test_bench_two_ranks_gloo():
     assert abs(out["value"] * out["ms_per_step"] * 3 / 1e3 - 2 * 3 * 16) < 1e-3 * 2 * 3 * 16 + 1
 
 
+def test_bench_starts_its_own_ranks_without_a_launcher():
+    """`python bench.py --gpus 2` (no torchrun around it) starts one rank per GPU itself and prints ONE line"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(OMP_NUM_THREADS="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "0", "--cpu-dry-run"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    assert json.loads(lines[0])["n_gpus"] == 2
+
+
 def test_game_id_sharding_is_disjoint():
     sys.path.insert(0, ROOT)
     import bench
