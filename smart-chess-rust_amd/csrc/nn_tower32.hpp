@@ -404,6 +404,13 @@ __global__ __launch_bounds__(256, SC_T32_OCC) void k_tower32(TowerArgs A) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i32 = lane & 31, h = lane >> 5;
     const NetDev& net = A.net;
+#ifdef SC_EXP
+    Stamp stampv;
+    stampv.on = A.dbg && A.dbg_stage == 2000 && lane == 0;
+    stampv.prev = 0;
+    for (int k = 0; k < 40; k++) stampv.t[k] = 0;
+    stampv.start();
+#endif
     const int bp[2] = {gpix2board(0, i32), gpix2board(1, i32)};            // this lane's two board pixels
     const int pixbase[2] = {hidx(bp[0]) * CP * 2, hidx(bp[1]) * CP * 2};   // their rows in the haloed image (bytes)
     const int px[2] = {pixbase[0] + h * 16, pixbase[1] + h * 16};          // + this lane's k half
@@ -472,13 +479,7 @@ __global__ __launch_bounds__(256, SC_T32_OCC) void k_tower32(TowerArgs A) {
         }
     };
 
-#ifdef SC_EXP
-    Stamp stampv;
-    stampv.on = A.dbg && A.dbg_stage == 2000 && lane == 0;
-    stampv.prev = 0;
-    for (int k = 0; k < 40; k++) stampv.t[k] = 0;
-    stampv.start();
-#endif
+    SC_MARK(38);   // prologue: input planes, zero fill, parameter staging
     // ---- conv_block (py/module.py:120-126): conv3x3 112->C (K padded to 128/tap), LN, ReLU
     {
         ch_load_lds<CT>(Bn, PAR0, wave, h);

@@ -9,7 +9,7 @@ g = np.load(os.path.join(ROOT, "tests", "golden", "nn_ref_b10_c256.npz"))
 boards = np.repeat(g["boards"], 32, axis=0)[:256]
 meta = np.repeat(g["meta"], 32, axis=0)[:256]
 names = ["conv1", "LN1 stats", "LN1 barrier", "LN1 norm", "store+barrier", "conv2", "LN2 stats", "LN2 barrier", "LN2 norm",
-         "pool", "pool barrier", "fc1+fc2", "resid+stores", "end barrier", "prologue+stem", "gather+end", "value head", "policy conv1+LN", "policy conv2+LN+scatter", "softmax", "v: conv", "v: bias+stats", "v: LN barrier", "v: LN apply", "p1: conv", "p1: stats", "p1: LN barrier", "p1: apply+store", "p2: conv", "p2: stats", "p2: LN barrier", "p2: apply", "p2: barrier", "stem: prologue", "stem: conv", "stem: stats", "stem: LN barrier", "stem: apply", "-", "-"]
+         "pool", "pool barrier", "fc1+fc2", "resid+stores", "end barrier", "prologue+stem", "gather+end", "value head", "policy conv1+LN", "policy conv2+LN+scatter", "softmax", "v: conv", "v: bias+stats", "v: LN barrier", "v: LN apply", "p1: conv", "p1: stats", "p1: LN barrier", "p1: apply+store", "p2: conv", "p2: stats", "p2: LN barrier", "p2: apply", "p2: barrier", "stem: prologue", "stem: conv", "stem: stats", "stem: LN barrier", "stem: apply", "prologue", "-"]
 for C in (128, 256):
     eng = scamd.Engine(10, C, seed=1)
     for _ in range(3):
