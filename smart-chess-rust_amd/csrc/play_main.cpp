@@ -86,6 +86,7 @@ static std::string out_name(const Args& a, int game_number) {
 }
 
 int main(int argc, char** argv) {
+    setenv("HIP_FORCE_DEV_KERNARG", "1", 0);   // kernel arguments in device memory; before any HIP call
     Args a;
     if (!parse(argc, argv, a)) return 2;
     if (a.white_device.empty()) {   // clap: required argument

@@ -182,6 +182,7 @@ static int run_gpu(const Args& a, int gpu, int first, int count, int* finished_w
 }
 
 int main(int argc, char** argv) {
+    setenv("HIP_FORCE_DEV_KERNARG", "1", 0);   // kernel arguments in device memory; before any HIP call
     Args a;
     if (!parse(argc, argv, a)) return 2;
     if (a.rollout_factor >= 0 && a.rollout_num > 0) {  // main.rs:74

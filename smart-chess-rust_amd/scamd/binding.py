@@ -2,6 +2,9 @@
 import ctypes as C
 import os
 
+# see INTEGRATION.md: kernel arguments in device memory (must precede HIP runtime initialisation)
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
