@@ -41,6 +41,17 @@ typedef struct sc_selfplay sc_selfplay;
 
 const char* sc_last_error(void);
 int sc_device_count(void);
+/* Launch-path state of the HIP runtime in this process, bit mask.  The engine's three launches per simulation step are
+ * ~6 % faster with kernel arguments in device memory (HIP_FORCE_DEV_KERNARG=1), which the HIP runtime reads ONCE, when
+ * it initialises:
+ *   bit 0  HIP_FORCE_DEV_KERNARG=1 is in the process environment
+ *   bit 1  ... and it was put there by this library's load hook (the host had not set it): it is effective only if the
+ *          host had not initialised HIP before loading libsc_engine.so -- which the library cannot observe.  Hosts that
+ *          load torch/tch first should export the variable themselves; then bit 1 is clear.
+ *   bit 2  the load hook was disabled by SC_ENGINE_KEEP_ENV=1 (the library never touches the environment)
+ * sc_engine_create leaves a note in sc_last_warning() when bit 0 is clear or bit 1 is set. */
+int sc_runtime_flags(void);
+const char* sc_last_warning(void);
 
 /* ------------------------------------------------------------------ network (L-predict) */
 typedef struct {
@@ -107,7 +118,10 @@ int sc_encode_steps(sc_engine* engine_or_null, int device_id, int n_games, const
                     int8_t* boards, int32_t* meta, float* dist, uint16_t* legal_idx, int32_t* n_legal, int32_t* status);
 
 /* ------------------------------------------------------------------ self-play (L-search) */
-enum { SC_EVAL_NET = 0, SC_EVAL_SYNTH = 1 }; /* SYNTH: integer-hash evaluator for exact search-parity tests */
+/* SYNTH: integer-hash evaluator for exact search-parity tests; SYNTH_COARSE: the same with 2-bit priors and values from
+ * {-0.5, 0, 0.5} (exact PUCT ties between some siblings); SYNTH_UNIFORM: uniform priors, value 0 (every unvisited sibling
+ * ties: find_max's last-maximum rule, src/mcts.rs:78-88, decides every descent) */
+enum { SC_EVAL_NET = 0, SC_EVAL_SYNTH = 1, SC_EVAL_SYNTH_COARSE = 2, SC_EVAL_SYNTH_UNIFORM = 3 };
 
 typedef struct {
     int32_t n_slots;            /* concurrent games on this GPU (BASELINE cfg2: 256) */
@@ -125,11 +139,19 @@ typedef struct {
     uint64_t seed;
     uint64_t first_game_id;     /* global id of this handle's first game (sharding across GPUs/ranks) */
     int32_t trace_capacity;     /* traces kept on the device: 0 = n_games (every trace retrievable); >0 = ring of that
-                                   many games (>= 2*n_slots), older traces are overwritten (throughput runs) */
+                                   many games (>= 2*n_slots): game k uses row k % capacity.  A row is never taken while
+                                   its previous game is still being played (the new game waits); a FINISHED trace is
+                                   overwritten (throughput runs) unless trace_hold is set */
     int32_t own_stream;         /* 1: this handle launches on its own HIP stream, so several handles (groups of games)
                                    of one engine overlap on the GPU: one group's tree work hides under another's network */
     int32_t tie_random;         /* temperature 0: 0 = first most-visited child (mcts::step, src/mcts.rs:298-306);
                                    1 = uniformly random among the most visited (NNPlayer::bestmove, src/play.rs:268-277) */
+    int32_t trace_hold;         /* 1: a finished trace stays in the ring until sc_selfplay_poll has handed it to the host and
+                                   the host has polled again; new games wait for a free row (streaming drain: the reference
+                                   writes each trace file when its game ends, src/main.rs:235-238) */
+    float rollout_factor;       /* > 0: -r/--rollout-factor (src/main.rs:29-30,175-176): every ply searches
+                                   min(300, (n_legal * factor) as i32) simulations, n_legal = legal moves of the ply's root;
+                                   rollout_num must then be 300 (it sizes the node pools) */
 } sc_selfplay_config;
 
 int sc_selfplay_create(sc_engine* engine_or_null, int device_id, const sc_selfplay_config* cfg, sc_selfplay** out);
@@ -177,9 +199,16 @@ typedef struct {
     int32_t winner;        /* 1 white, 0 black, -1 none */
     uint64_t game_id;
 } sc_trace_info;
+/* Returns 0 ok, 1 the game has not finished yet, 2 its trace is no longer on the device (ring row overwritten by a
+ * later game, or released by sc_selfplay_poll), < 0 error. */
 int sc_selfplay_get_trace(sc_selfplay*, int game /*0..n_games-1*/, sc_trace_info* info, uint16_t* step_move,
                           float* step_q, int32_t* child_off, uint16_t* child_move, int32_t* child_n, float* child_q,
                           float* child_uct);
+/* Streaming drain: completes the enqueued work, then returns the number of games (written to
+ * finished_games[0..cap), handle-local indices usable with sc_selfplay_get_trace / _write_trace_json) that have finished
+ * since they were last reported.  With trace_hold the traces reported by the PREVIOUS call are released first (their ring
+ * rows become free for new games), so the host reads each batch between two polls.  < 0: error. */
+int sc_selfplay_poll(sc_selfplay*, int32_t* finished_games, int cap);
 /* Writes the reference's trace JSON (src/trace.rs:23-32; serde_json pretty, keys "outcome","steps"). */
 int sc_selfplay_write_trace_json(sc_selfplay*, int game, const char* path);
 
@@ -205,6 +234,13 @@ int sc_selfplay_set_search(sc_selfplay*, float cpuct, float epsilon, int with_no
  * (sc_selfplay_set_position + sc_selfplay_enqueue_sims + sc_selfplay_get_tree). */
 int sc_search(sc_engine*, const uint16_t* moves, int n_moves, int rollout, float cpuct, int with_noise, uint64_t seed, int cap,
               uint16_t* child_move, int32_t* child_n, float* child_q, float* child_prior, float* root_q);
+
+/* test aid: find_max (src/mcts.rs:78-88, Iterator::max_by: the LAST maximum wins) as the descent computes it, on n <= 256
+ * caller-provided finite values: out[0] = the one-round form used for nodes with <= 64 children (-2 if n > 64),
+ * out[1] = the four-round (value, index) form used for wider nodes. */
+int sc_debug_find_max(int device_id, const float* values, int n, int32_t* out2);
+/* developer aid: cycle stamps of the last search-kernel launch, out[n_slots][8] (tools/dbg_cycles.py) */
+int sc_selfplay_debug_cycles(sc_selfplay*, int enable, unsigned long long* out);
 
 /* utility: trace-file JSON writer on caller-provided arrays (no GPU needed) */
 int sc_trace_write_json(const char* path, const sc_trace_info* info, const uint16_t* step_move, const float* step_q,

@@ -61,6 +61,35 @@ void orc_eval_synth(void* user, const orc_state* st, int n_legal, const orc_move
     *value = (float)v / 8388608.0f;
 }
 
+/* Test evaluators that make exact PUCT ties (the hash evaluator's 24-bit priors never collide): find_max keeps the LAST
+ * maximum (src/mcts.rs:78-88).  COARSE: 2-bit weights, values from {-0.5, 0, 0.5}; UNIFORM: equal priors, value 0. */
+void orc_eval_synth_coarse(void* user, const orc_state* st, int n_legal, const orc_move* legal, const int* legal_idx,
+                           float* priors, float* value) {
+    (void)legal_idx;
+    uint64_t h = orc_pos_hash(st) ^ (user ? *(const uint64_t*)user : 0);
+    uint64_t sum = 0;
+    uint32_t w[ORC_MAX_MOVES];
+    for (int i = 0; i < n_legal; i++) {
+        uint32_t full = 1u + (uint32_t)(orc_mix64(h ^ ((uint64_t)legal[i] * 0x9E3779B97F4A7C15ULL)) >> 40);
+        w[i] = 1u + (full >> 22);
+        sum += w[i];
+    }
+    float fs = (float)sum;
+    for (int i = 0; i < n_legal; i++) priors[i] = (float)w[i] / fs;
+    int64_t v = (int64_t)(orc_mix64(h ^ 0xABCDEFULL) >> 40) - 8388608;
+    float fv = (float)v / 8388608.0f;
+    *value = fv < -0.5f ? -0.5f : fv >= 0.5f ? 0.5f : 0.0f;
+}
+void orc_eval_synth_uniform(void* user, const orc_state* st, int n_legal, const orc_move* legal, const int* legal_idx,
+                            float* priors, float* value) {
+    (void)user;
+    (void)st;
+    (void)legal;
+    (void)legal_idx;
+    for (int i = 0; i < n_legal; i++) priors[i] = 1.0f / (float)n_legal;
+    *value = 0.0f;
+}
+
 void orc_eval_net(void* user, const orc_state* st, int n_legal, const orc_move* legal, const int* legal_idx,
                   float* priors, float* value) {
     (void)legal;
@@ -330,9 +359,16 @@ orc_trace* orc_selfplay_game(const orc_selfplay_cfg* cfg, orc_eval_fn eval, void
         float temperature = i < cfg->temperature_switch ? 1.0f : cfg->temperature;
         orc_search* s = orc_search_new(st, depth);
         orc_search_set_rng(s, orc_rng(cfg->seed, cfg->game_id, (uint64_t)i, 2, 0));
-        for (int r = 0; r < cfg->rollout_num; r++)
+        /* main.rs:175-180: (Some(v), None) => i32::min(300, (state.legal_moves().len() as f32 * v) as i32) */
+        int rollout = cfg->rollout_num;
+        if (cfg->rollout_factor > 0.0f) {
+            orc_move lm[ORC_MAX_MOVES];
+            int r = (int)((float)orc_legal_moves(st, lm) * cfg->rollout_factor);
+            rollout = r < 300 ? r : 300;
+        }
+        for (int r = 0; r < rollout; r++)
             orc_search_sim(s, eval, user, cfg->cpuct, cfg->epsilon, cfg->with_noise, NULL, cfg->faithful);
-        tr->n_sims += cfg->rollout_num;
+        tr->n_sims += rollout;
         tr->n_evals += s->n_evals;
         node_t* root = &s->nodes[0];
         int nc = root->n_child;

@@ -56,6 +56,7 @@ class SelfplayCfg(C.Structure):
         ("seed", C.c_uint64),
         ("game_id", C.c_uint64),
         ("outcome_gate", C.c_int),
+        ("rollout_factor", C.c_float),
     ]
 
 
@@ -334,10 +335,10 @@ class Search:
 
 def selfplay_game(evaluator="orc_eval_synth", user=None, rollout_num=20, num_steps=150, cpuct=2.5,
                   temperature=0.0, temperature_switch=4, epsilon=0.15, with_noise=True, faithful=False, seed=0,
-                  game_id=0, outcome_gate=100):
+                  game_id=0, outcome_gate=100, rollout_factor=0.0):
     L = lib()
     cfg = SelfplayCfg(rollout_num, num_steps, cpuct, temperature, temperature_switch, epsilon, int(with_noise),
-                      int(faithful), seed, game_id, outcome_gate)
+                      int(faithful), seed, game_id, outcome_gate, rollout_factor)
     ev = evaluator if not isinstance(evaluator, str) else eval_fn(evaluator)
     tp = L.orc_selfplay_game(C.byref(cfg), ev, user)
     t = tp.contents
@@ -373,7 +374,7 @@ def match_game(white="orc_eval_synth", user_white=None, black="orc_eval_synth", 
                cpuct=1.5, temperature=0.0, temperature_switch=0, faithful=False, seed=0, game_id=0):
     """src/play.rs:241-343 with two evaluators; user_* for the synthetic evaluator = an int salt (or None)"""
     L = lib()
-    cfg = SelfplayCfg(rollout_num, num_steps, cpuct, temperature, temperature_switch, 0.15, 0, int(faithful), seed, game_id, -1)
+    cfg = SelfplayCfg(rollout_num, num_steps, cpuct, temperature, temperature_switch, 0.15, 0, int(faithful), seed, game_id, -1, 0.0)
     keep = []
 
     def prep(ev, user):

@@ -15,6 +15,8 @@ typedef void (*orc_eval_fn)(void* user, const orc_state* st, int n_legal, const 
 
 /* built-in evaluators */
 void orc_eval_synth(void* user, const orc_state*, int, const orc_move*, const int*, float*, float*); /* integer-hash priors/values, bit-reproducible on the GPU */
+void orc_eval_synth_coarse(void* user, const orc_state*, int, const orc_move*, const int*, float*, float*);  /* 2-bit priors, values {-0.5,0,0.5}: exact ties */
+void orc_eval_synth_uniform(void* user, const orc_state*, int, const orc_move*, const int*, float*, float*); /* uniform priors, value 0: every unvisited sibling ties */
 void orc_eval_net(void* user /* orc_net* */, const orc_state*, int, const orc_move*, const int*, float*, float*);
 
 /* shared, exactly specified helpers (the engine implements the same functions) */
@@ -67,6 +69,7 @@ typedef struct {
     uint64_t seed;
     uint64_t game_id;
     int outcome_gate;       /* src/main.rs:223: outcome is only looked at when i > 100 */
+    float rollout_factor;   /* > 0: --rollout-factor, per-ply budget min(300, n_legal * factor) (src/main.rs:175-176) */
 } orc_selfplay_cfg;
 
 /* src/main.rs:155-238 */

@@ -6,11 +6,13 @@
 // many concurrent games per GPU.  All compute runs on the GPU; there is no CPU fallback: every
 // entry point fails with an error code if HIP or the device is unavailable.
 #include <hip/hip_runtime.h>
+#include <stddef.h>
 #include <stdio.h>
 #include <string.h>
 
 #include <algorithm>
 #include <string>
+#include <utility>
 #include <initializer_list>
 #include <vector>
 
@@ -26,6 +28,7 @@ static void dfree(std::initializer_list<void*> ptrs) {
 }
 
 static thread_local std::string g_err;
+static thread_local std::string g_warn;
 static int fail(const std::string& m, int code = -1) {
     g_err = m;
     return code;
@@ -47,7 +50,7 @@ struct sc_engine {
     scnn::NetDev net{};
     uint16_t* d_wb = nullptr;
     float* d_wf = nullptr;
-    int ksplit = getenv("SC_KSPLIT") ? atoi(getenv("SC_KSPLIT")) : 64;   // split-K of value_head.ffn.0 (16, 32 or 64)
+    int ksplit = 64;   // split-K of value_head.ffn.0 (the search kernel's fused tail sums 32 or 64 partials)
     // scratch, grown on demand
     int cap = 0;
     int8_t* d_boards = nullptr;
@@ -144,11 +147,28 @@ int sc_device_count(void) {
 // trip for its argument block -- three launches per simulation step, +6 % simulations/s measured.  The HIP runtime reads the
 // switch when it initialises, so it is set when this library is loaded (no effect if the host application has already
 // initialised HIP: export HIP_FORCE_DEV_KERNARG=1 there).  An explicit setting of the host wins.
+// SC_ENGINE_KEEP_ENV=1 disables the hook.  sc_runtime_flags() reports what happened (include/sc_engine.h).
 namespace {
 struct RuntimeEnv {
-    RuntimeEnv() { setenv("HIP_FORCE_DEV_KERNARG", "1", 0); }
+    int flags = 0;
+    RuntimeEnv() {
+        const char* keep = getenv("SC_ENGINE_KEEP_ENV");
+        if (keep && keep[0] == '1') {
+            flags |= 4;
+        } else if (!getenv("HIP_FORCE_DEV_KERNARG")) {
+            setenv("HIP_FORCE_DEV_KERNARG", "1", 0);
+            flags |= 2;
+        }
+    }
 } g_runtime_env;
 }  // namespace
+
+int sc_runtime_flags(void) {
+    const char* v = getenv("HIP_FORCE_DEV_KERNARG");
+    const int on = (v && v[0] == '1' && v[1] == 0) ? 1 : 0;
+    return on | (on ? (g_runtime_env.flags & 2) : 0) | (g_runtime_env.flags & 4);
+}
+const char* sc_last_warning(void) { return g_warn.c_str(); }
 
 int sc_engine_create(const sc_net_config* cfg, const char* weights_path, int device_id, sc_engine** out) {
     if (!cfg || !out) return fail("null argument");
@@ -175,19 +195,33 @@ int sc_engine_create(const sc_net_config* cfg, const char* weights_path, int dev
     scw::Packed pk = scw::pack(hw, v32);
     sc_engine* e = new sc_engine();
     e->device = device_id;
+    // every failure from here on goes through sc_engine_destroy (stream, weight blobs)
+    auto bail = [&](hipError_t err, const char* what) {
+        std::string m = std::string(what) + ": " + hipGetErrorString(err);
+        sc_engine_destroy(e);
+        return fail(m, -2);
+    };
     const char* ierr = scl::nn_init();
     if (ierr) {
-        delete e;
+        sc_engine_destroy(e);
         return fail(std::string("kernel attribute setup failed: ") + ierr);
     }
-    HIPOK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
-    HIPOK(dalloc(&e->d_wb, pk.wb.size()));
-    HIPOK(dalloc(&e->d_wf, pk.wf.size()));
-    HIPOK(hipMemcpy(e->d_wb, pk.wb.data(), pk.wb.size() * 2, hipMemcpyHostToDevice));
-    HIPOK(hipMemcpy(e->d_wf, pk.wf.data(), pk.wf.size() * 4, hipMemcpyHostToDevice));
+    hipError_t he;
+    if ((he = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking)) != hipSuccess) return bail(he, "hipStreamCreate");
+    if ((he = dalloc(&e->d_wb, pk.wb.size())) != hipSuccess) return bail(he, "hipMalloc(weights)");
+    if ((he = dalloc(&e->d_wf, pk.wf.size())) != hipSuccess) return bail(he, "hipMalloc(parameters)");
+    if ((he = hipMemcpy(e->d_wb, pk.wb.data(), pk.wb.size() * 2, hipMemcpyHostToDevice)) != hipSuccess) return bail(he, "hipMemcpy(weights)");
+    if ((he = hipMemcpy(e->d_wf, pk.wf.data(), pk.wf.size() * 4, hipMemcpyHostToDevice)) != hipSuccess) return bail(he, "hipMemcpy(parameters)");
     static_cast<scnn::NetLayout&>(e->net) = pk.lay;
     e->net.wb = e->d_wb;
     e->net.wf = e->d_wf;
+    const int rf = sc_runtime_flags();
+    g_warn.clear();
+    if (!(rf & 1))
+        g_warn = "HIP_FORCE_DEV_KERNARG=1 is not set: kernel arguments travel through host-coherent memory (about -6 % simulations/s)";
+    else if (rf & 2)
+        g_warn = "HIP_FORCE_DEV_KERNARG=1 was set by libsc_engine's load hook: it has no effect if the host initialised HIP before "
+                 "loading the library (export it in the host's environment instead)";
     *out = e;
     return 0;
 }
@@ -195,11 +229,11 @@ int sc_engine_create(const sc_net_config* cfg, const char* weights_path, int dev
 void sc_engine_destroy(sc_engine* e) {
     if (!e) return;
     (void)hipSetDevice(e->device);
-    (void)hipStreamSynchronize(e->stream);
+    if (e->stream) (void)hipStreamSynchronize(e->stream);
     engine_free_scratch(e);
     dfree({e->d_wb});
     dfree({e->d_wf});
-    (void)hipStreamDestroy(e->stream);
+    if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
 }
 
@@ -340,7 +374,8 @@ int sc_encode_positions(sc_engine* e, int device_id, int n, const uint16_t* move
     };
     if (total) ok(hipMemcpyAsync(d_moves, moves, (size_t)total * 2, hipMemcpyHostToDevice, st));
     ok(hipMemcpyAsync(d_off, move_off, ((size_t)n + 1) * 4, hipMemcpyHostToDevice, st));
-    ok(hipMemsetAsync(d_lm, 0, (size_t)n * 448 * 2, st));   // d_lm and d_li are adjacent in the arena
+    ok(hipMemsetAsync(d_lm, 0, (size_t)n * 448, st));   // rows are zero past n_legal (take() pads each region to 256 B:
+    ok(hipMemsetAsync(d_li, 0, (size_t)n * 448, st));   // the two tables are not adjacent in general)
     if (!rc) scl::encode_positions(n, d_moves, d_off, nullptr, d_hist, hist_cap, d_boards, d_meta, d_lm, d_li, d_nl, d_out, st);
     ok(hipGetLastError());
     if (boards) ok(hipMemcpyAsync(boards, d_boards, (size_t)n * 7168, hipMemcpyDeviceToHost, st));
@@ -475,6 +510,9 @@ struct sc_selfplay {
     uint64_t salt[2] = {0, 0};
     scnn::bf16_t* d_hval = nullptr;  // value-head features of the current leaves [n_slots][64][256]
     float* d_vpart = nullptr;        // split-K partials of value_head.ffn.0 [ksplit][n_slots][128]
+    // streaming drain (sc_selfplay_poll): per trace-ring row, the game id last reported to the host (+1; 0 = none)
+    std::vector<uint64_t> reported;
+    std::vector<int> to_release;     // rows handed out by the previous poll (trace_hold)
 };
 
 // complete the last enqueued simulation (expand / backward / ply transition) so that host reads see a
@@ -515,6 +553,9 @@ int sc_selfplay_create(sc_engine* e, int device_id, const sc_selfplay_config* cf
     if (cfg->n_slots <= 0 || cfg->n_games <= 0 || cfg->rollout_num < 1 || cfg->num_steps < 1 || cfg->num_steps > 4000)
         return fail("bad self-play configuration");
     if (cfg->rollout_num > 60000) return fail("rollout_num too large");
+    if (cfg->evaluator < SC_EVAL_NET || cfg->evaluator > SC_EVAL_SYNTH_UNIFORM) return fail("unknown evaluator");
+    if (cfg->rollout_factor < 0.f || (cfg->rollout_factor > 0.f && cfg->rollout_num != 300))
+        return fail("rollout_factor needs rollout_num = 300 (the cap of min(300, n_legal * factor), src/main.rs:176)");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail("no HIP device available: libsc_engine has no CPU fallback", -3);
     int dev = e ? e->device : device_id;
@@ -524,10 +565,20 @@ int sc_selfplay_create(sc_engine* e, int device_id, const sc_selfplay_config* cf
     sp->engine = e;
     sp->device = dev;
     sp->cfg = *cfg;
+    // every failure from here on goes through sc_selfplay_destroy
+    auto bail = [&](hipError_t err, const char* what) {
+        std::string m = std::string(what) + ": " + hipGetErrorString(err);
+        sc_selfplay_destroy(sp);
+        return fail(m, -2);
+    };
     if (e && !cfg->own_stream) {
         sp->stream = e->stream;
     } else {
-        HIPOK(hipStreamCreateWithFlags(&sp->stream, hipStreamNonBlocking));
+        hipError_t he = hipStreamCreateWithFlags(&sp->stream, hipStreamNonBlocking);
+        if (he != hipSuccess) {
+            sp->stream = nullptr;
+            return bail(he, "hipStreamCreate");
+        }
         sp->own_stream = true;
     }
     sc::SpParams& p = sp->p;
@@ -540,6 +591,8 @@ int sc_selfplay_create(sc_engine* e, int device_id, const sc_selfplay_config* cf
     p.evaluator = cfg->evaluator;
     p.external_noise = cfg->external_noise;
     p.tie_random = cfg->tie_random;
+    p.trace_hold = cfg->trace_hold ? 1 : 0;
+    p.rollout_factor = cfg->rollout_factor;
     p.synth_salt = 0;
     p.cpuct = cfg->cpuct;
     p.temperature = cfg->temperature;
@@ -596,7 +649,6 @@ int sc_selfplay_create(sc_engine* e, int device_id, const sc_selfplay_config* cf
         }
     }
     if (e && cfg->evaluator == SC_EVAL_NET) {
-        if (e->ksplit != 32 && e->ksplit != 64) return fail("split-K of the value head must be 32 or 64");
         rc |= sp_alloc(sp, &sp->d_hval, G * 64 * 256);
         rc |= sp_alloc(sp, &sp->d_vpart, (size_t)e->ksplit * G * 128);
         if (rc) {
@@ -612,12 +664,14 @@ int sc_selfplay_create(sc_engine* e, int device_id, const sc_selfplay_config* cf
         p.vf_fc2w = (uint32_t)e->net.f_fc2w;
         p.vf_fc2b = (uint32_t)e->net.f_fc2b;
     }
+    sp->reported.assign((size_t)p.trace_cap, 0);
     // the zero-fills above ran on the NULL stream, which does not order against the (non-blocking) launch
     // stream: make them complete before the first kernel touches the buffers
-    HIPOK(hipDeviceSynchronize());
+    hipError_t he = hipDeviceSynchronize();
+    if (he != hipSuccess) return bail(he, "hipDeviceSynchronize");
     scl::init_slots(p, sp->stream);
-    HIPOK(hipGetLastError());
-    HIPOK(hipStreamSynchronize(sp->stream));
+    if ((he = hipGetLastError()) != hipSuccess) return bail(he, "k_init_slots");
+    if ((he = hipStreamSynchronize(sp->stream)) != hipSuccess) return bail(he, "k_init_slots");
     *out = sp;
     return 0;
 }
@@ -626,11 +680,12 @@ void sc_selfplay_destroy(sc_selfplay* sp) {
     if (!sp) return;
     (void)hipSetDevice(sp->device);
     if (sp->stream) (void)hipStreamSynchronize(sp->stream);
+    else (void)hipDeviceSynchronize();
     for (void* a : sp->allocs) (void)hipFree(a);
     for (hipEvent_t ev : sp->ev) (void)hipEventDestroy(ev);
     if (sp->ev_begin) (void)hipEventDestroy(sp->ev_begin);
     if (sp->ev_end) (void)hipEventDestroy(sp->ev_end);
-    if (sp->own_stream) (void)hipStreamDestroy(sp->stream);
+    if (sp->own_stream && sp->stream) (void)hipStreamDestroy(sp->stream);
     delete sp;
 }
 
@@ -671,7 +726,7 @@ int sc_selfplay_enqueue_sims(sc_selfplay* sp, int n) {
         }
         // finish the previous simulation (expand/backward/ply transition) and select + encode the next leaf
         scl::mcts(q, 1, 1, s);
-        if (p.evaluator == SC_EVAL_SYNTH) {
+        if (p.evaluator != SC_EVAL_NET) {
             scl::synth_eval(q, s);
         } else {
             bool timed = sp->timing_stride > 0 && (sp->nn_launches % sp->timing_stride) == 0;
@@ -721,6 +776,7 @@ int sc_selfplay_set_players(sc_selfplay* sp, sc_engine* white, sc_engine* black,
     if (!sp) return fail("null handle");
     if (sp->sim_steps_enqueued != 0) return fail("set_players must precede the first enqueue");
     if (sp->cfg.n_games != sp->cfg.n_slots) return fail("match play needs n_games == n_slots (lockstep plies, no slot recycling)");
+    if (sp->cfg.rollout_factor > 0.f) return fail("match play needs a fixed rollout (lockstep plies)");
     if (sp->cfg.evaluator == SC_EVAL_NET) {
         if (!white || !black) return fail("match play with SC_EVAL_NET needs two engines");
         if (white->device != sp->device || black->device != sp->device) return fail("both engines must live on the handle's device");
@@ -765,7 +821,7 @@ int sc_selfplay_get_stats(sc_selfplay* sp, sc_selfplay_stats* out) {
     std::vector<sc::GameCtl> ctl((size_t)sp->p.n_slots);
     HIPOK(hipMemcpy(ctl.data(), sp->p.ctl, ctl.size() * sizeof(sc::GameCtl), hipMemcpyDeviceToHost));
     int active = 0;
-    for (auto& g : ctl) active += g.status == sc::ST_ACTIVE;
+    for (auto& g : ctl) active += g.status == sc::ST_ACTIVE || g.status == sc::ST_PENDING;
     std::vector<unsigned long long> sc((size_t)sp->p.n_slots * 2);
     HIPOK(hipMemcpy(sc.data(), sp->p.slot_cnt, sc.size() * 8, hipMemcpyDeviceToHost));
     unsigned long long sims = 0, evals = 0;
@@ -784,6 +840,8 @@ int sc_selfplay_get_stats(sc_selfplay* sp, sc_selfplay_stats* out) {
 
 int sc_selfplay_run(sc_selfplay* sp, int64_t max_sim_steps) {
     if (!sp) return fail("null handle");
+    if (sp->p.trace_hold && sp->p.trace_cap < sp->p.total_games)
+        return fail("trace_hold with a ring smaller than n_games: drive the handle with sc_selfplay_enqueue_sims + sc_selfplay_poll");
     int64_t done = 0;
     for (;;) {
         int chunk = sp->p.rollout;
@@ -831,6 +889,7 @@ int sc_selfplay_timing(sc_selfplay* sp, int reset, float* ms_total, float* ms_nn
 int sc_selfplay_get_trace(sc_selfplay* sp, int game, sc_trace_info* info, uint16_t* step_move, float* step_q,
                           int32_t* child_off, uint16_t* child_move, int32_t* child_n, float* child_q, float* child_uct) {
     if (!sp || !info || game < 0 || game >= sp->p.total_games) return fail("bad argument");
+    const uint64_t want_id = sp->p.first_game_id + (uint64_t)game;
     game %= sp->p.trace_cap;
     HIPOK(hipSetDevice(sp->device));
     sp_flush(sp);
@@ -838,7 +897,12 @@ int sc_selfplay_get_trace(sc_selfplay* sp, int game, sc_trace_info* info, uint16
     const sc::SpParams& p = sp->p;
     sc::TraceHdr h;
     HIPOK(hipMemcpy(&h, p.thdr + game, sizeof h, hipMemcpyDeviceToHost));
-    if (!h.done) return fail("game not finished", 1);
+    // the ring row may belong to an earlier game (this one has not started), to a later one (overwritten) or be released
+    if (h.state == sc::TR_FREE) return fail(sp->reported[(size_t)game] > want_id ? "trace released or overwritten" : "game not finished",
+                                            sp->reported[(size_t)game] > want_id ? 2 : 1);
+    if (h.game_id < want_id) return fail("game not finished", 1);
+    if (h.game_id > want_id) return fail("trace overwritten by a later game (trace_capacity ring)", 2);
+    if (h.state != sc::TR_DONE) return fail("game not finished", 1);
     const size_t S = (size_t)p.num_steps, base = (size_t)game * S;
     int ns = h.n_steps;
     std::vector<int32_t> nch((size_t)std::max(ns, 1));
@@ -873,6 +937,54 @@ int sc_selfplay_get_trace(sc_selfplay* sp, int game, sc_trace_info* info, uint16
             off += (int)n;
         }
     }
+    return 0;
+}
+
+int sc_selfplay_poll(sc_selfplay* sp, int32_t* finished_games, int cap) {
+    if (!sp || cap < 0 || (cap > 0 && !finished_games)) return fail("bad argument");
+    HIPOK(hipSetDevice(sp->device));
+    sp_flush(sp);
+    HIPOK(hipStreamSynchronize(sp->stream));
+    const sc::SpParams& p = sp->p;
+    // rows handed out by the previous poll go back to the device (the stream is idle: no kernel reads them now)
+    for (int row : sp->to_release) {
+        const int32_t free_state = sc::TR_FREE;
+        HIPOK(hipMemcpy(reinterpret_cast<char*>(p.thdr + row) + offsetof(sc::TraceHdr, state), &free_state, 4, hipMemcpyHostToDevice));
+    }
+    sp->to_release.clear();
+    std::vector<sc::TraceHdr> hdr((size_t)p.trace_cap);
+    HIPOK(hipMemcpy(hdr.data(), p.thdr, hdr.size() * sizeof(sc::TraceHdr), hipMemcpyDeviceToHost));
+    // oldest games first: a consumer that writes trace{N}.json sees them in the order the reference's jobs would finish
+    std::vector<std::pair<uint64_t, int>> fin;
+    for (int row = 0; row < p.trace_cap; row++) {
+        const sc::TraceHdr& h = hdr[(size_t)row];
+        if (h.state == sc::TR_DONE && sp->reported[(size_t)row] != h.game_id + 1) fin.emplace_back(h.game_id, row);
+    }
+    std::sort(fin.begin(), fin.end());
+    int n = 0;
+    for (auto& f : fin) {
+        if (n >= cap) break;
+        finished_games[n++] = (int32_t)(f.first - p.first_game_id);
+        sp->reported[(size_t)f.second] = f.first + 1;
+        if (p.trace_hold) sp->to_release.push_back(f.second);
+    }
+    return n;
+}
+
+int sc_debug_find_max(int device_id, const float* values, int n, int32_t* out2) {
+    if (!values || !out2 || n < 1 || n > 256) return fail("bad argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail("no HIP device available: libsc_engine has no CPU fallback", -3);
+    HIPOK(hipSetDevice(device_id));
+    float* d_u = nullptr;
+    int* d_o = nullptr;
+    HIPOK(dalloc(&d_u, 256));
+    HIPOK(dalloc(&d_o, 2));
+    HIPOK(hipMemcpy(d_u, values, (size_t)n * 4, hipMemcpyHostToDevice));
+    scl::debug_find_max(d_u, n, d_o, nullptr);
+    hipError_t e1 = hipGetLastError(), e2 = hipMemcpy(out2, d_o, 8, hipMemcpyDeviceToHost);
+    dfree({d_u, d_o});
+    if (e1 != hipSuccess || e2 != hipSuccess) return fail(hipGetErrorString(e1 != hipSuccess ? e1 : e2), -2);
     return 0;
 }
 
@@ -971,6 +1083,12 @@ int sc_selfplay_set_position(sc_selfplay* sp, int slot, const uint16_t* moves, i
     if (!sp || slot < 0 || slot >= sp->p.n_slots || n_moves < 0 || n_moves > 590) return fail("bad argument");
     HIPOK(hipSetDevice(sp->device));
     sp_flush(sp);
+    {
+        HIPOK(hipStreamSynchronize(sp->stream));
+        sc::GameCtl c;
+        HIPOK(hipMemcpy(&c, sp->p.ctl + slot, sizeof c, hipMemcpyDeviceToHost));
+        if (c.status == sc::ST_PENDING) return fail("slot is waiting for a trace-ring row: no game to reposition");
+    }
     uint16_t* d_moves = nullptr;
     HIPOK(dalloc(&d_moves, (size_t)n_moves));
     if (n_moves) HIPOK(hipMemcpy(d_moves, moves, (size_t)n_moves * 2, hipMemcpyHostToDevice));
@@ -995,11 +1113,11 @@ int sc_selfplay_set_search(sc_selfplay* sp, float cpuct, float epsilon, int with
 // (src/lib.rs:233-247) as a single call; see include/sc_engine.h
 int sc_search(sc_engine* e, const uint16_t* moves, int n_moves, int rollout, float cpuct, int with_noise, uint64_t seed,
               int cap, uint16_t* child_move, int32_t* child_n, float* child_q, float* child_prior, float* root_q) {
-    if (!e || rollout < 1 || rollout > 60000 || cap < 0) return fail("bad argument");
+    if (!e || rollout < 1 || rollout >= 60000 || cap < 0) return fail("bad argument");
     sc_selfplay_config c{};
     c.n_slots = 1;
     c.n_games = 1;
-    c.rollout_num = 60000;     // the per-ply budget of the self-play driver: never reached here
+    c.rollout_num = rollout + 1;   // sizes the node pool; one more than the call runs, so no ply transition happens
     c.num_steps = 4000;
     c.cpuct = cpuct;
     c.epsilon = 0.15f;         // mcts::mcts(.., 0.15, noise) at both call sites
@@ -1044,7 +1162,7 @@ int sc_move_uci(uint16_t move, char* buf8) { return sctrace::move_uci(move, buf8
 // the side to move (Black's moves are rotated first); -1 if the move has no index.  Pure integer host function.
 int sc_move_index(uint16_t move, int white_to_move) { return sc::move_index((sc::move_t)move, white_to_move ? sc::WHITE : sc::BLACK); }
 
-/* developer aid (not in the public header): cycle stamps of the last k_mcts launch, out[n_slots][8] */
+/* developer aid: cycle stamps of the last k_mcts launch, out[n_slots][8] */
 int sc_selfplay_debug_cycles(sc_selfplay* sp, int enable, unsigned long long* out) {
     if (!sp) return fail("null handle");
     HIPOK(hipSetDevice(sp->device));

@@ -10,6 +10,7 @@ namespace scl {
 void init_slots(const sc::SpParams& p, hipStream_t s);
 void mcts(const sc::SpParams& p, int do_expand, int do_select, hipStream_t s);
 void synth_eval(const sc::SpParams& p, hipStream_t s);
+void debug_find_max(const float* d_u, int n, int* d_out, hipStream_t s);
 void set_position(const sc::SpParams& p, int slot, const uint16_t* d_moves, int n_moves, hipStream_t s);
 void encode_positions(int n_pos, const uint16_t* d_moves, const uint32_t* d_move_off, const uint32_t* d_move_len, sc::Position* d_hist,
                       int hist_cap, int8_t* boards, int32_t* meta, uint16_t* legal_mv, uint16_t* legal_idx, int32_t* n_legal,

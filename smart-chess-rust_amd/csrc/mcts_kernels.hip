@@ -10,6 +10,7 @@ void mcts(const sc::SpParams& p, int do_expand, int do_select, hipStream_t s) {
     hipLaunchKernelGGL(sc::k_mcts, dim3(p.n_slots), dim3(64), 0, s, p, do_expand, do_select);
 }
 void synth_eval(const sc::SpParams& p, hipStream_t s) { hipLaunchKernelGGL(sc::k_synth_eval, dim3(p.n_slots), dim3(64), 0, s, p); }
+void debug_find_max(const float* d_u, int n, int* d_out, hipStream_t s) { hipLaunchKernelGGL(sc::k_debug_find_max, dim3(1), dim3(64), 0, s, d_u, n, d_out); }
 void set_position(const sc::SpParams& p, int slot, const uint16_t* d_moves, int n_moves, hipStream_t s) {
     hipLaunchKernelGGL(sc::k_set_position, dim3(1), dim3(64), 0, s, p, slot, d_moves, n_moves);
 }

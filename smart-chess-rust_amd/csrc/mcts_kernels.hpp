@@ -154,7 +154,7 @@ __device__ __forceinline__ GameCtl uniform(const GameCtl& q) {
     r.trace_slot = uniform(q.trace_slot);
     r.game_id = uniform((bb_t)q.game_id);
     r.start_ply = uniform(q.start_ply);
-    r.pad = 0;
+    r.rollout_cur = uniform(q.rollout_cur);
     return r;
 }
 
@@ -514,6 +514,12 @@ __device__ __forceinline__ void dev_select(const SpParams& p, int g, int lane, i
     bool in_check = gen_legal_wave(pos, s_moves, lane, n);   // lane = square (chess_rules_wave.hpp)
     __syncthreads();
     SC_STAMP(5);
+    // --rollout-factor (src/main.rs:175-176): the ply's budget follows from the root's legal-move count, known here at
+    // the first simulation of the ply (the only one whose leaf is the root)
+    if (depth == 0 && p.rollout_factor > 0.f && lane == 0) {
+        const int r = (int)((float)n * p.rollout_factor);
+        c.rollout_cur = r < 300 ? r : 300;
+    }
     if (n == 0) {
         if (lane == 0) {
             c.leaf_kind = LK_TERM_NEW;
@@ -550,6 +556,35 @@ __device__ __forceinline__ void dev_select(const SpParams& p, int g, int lane, i
     SC_STAMP(6);
 }
 
+// ------------------------------------------------------------------ find_max on given values (test aid, sc_debug_find_max)
+// The two argmax forms of the descent on caller-provided PUCT values: out[0] = one-round form (n <= 64, lane = child),
+// out[1] = four-round (value, index) pair form (n <= 256, lane owns children lane, lane+64, ...), exactly as `level`
+// above combines them.  Lets a test place exact ties, -0.0 / +0.0 pairs and maxima in any lane and round.
+__global__ __launch_bounds__(64) void k_debug_find_max(const float* u, int n, int* out) {
+    const int lane = threadIdx.x;
+    if (n <= 64) {
+        const int r = wave_argmax_last_lane(lane < n ? u[lane] : 0.f, lane < n);
+        if (lane == 0) out[0] = r;
+    } else if (lane == 0) {
+        out[0] = -2;
+    }
+    float best_u = 0.f;
+    int best_i = -1;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int i = lane + 64 * r;
+        if (i < n) {
+            const float v = u[i];
+            if (best_i < 0 || v >= best_u) {
+                best_u = v;
+                best_i = i;
+            }
+        }
+    }
+    const int r4 = wave_argmax_last(best_u, best_i);
+    if (lane == 0) out[1] = r4;
+}
+
 // ------------------------------------------------------------------ synthetic evaluator (tests)
 __global__ __launch_bounds__(64) void k_synth_eval(SpParams p) {
     const int g = blockIdx.x, lane = threadIdx.x;
@@ -559,24 +594,43 @@ __global__ __launch_bounds__(64) void k_synth_eval(SpParams p) {
     uint64_t h = synth_pos_hash(pos) ^ p.synth_salt;
     int n = c.n_legal;
     const uint16_t* lm = p.legal_mv + (size_t)g * MAXC;
+    if (p.evaluator == SYNTH_UNIFORM) {
+        // tie tests: every sibling has the same prior and every leaf the value 0, so all unvisited children of a node tie
+        // exactly and find_max's LAST-maximum rule (src/mcts.rs:78-88) decides every descent
+        for (int i = lane; i < n; i += 64) p.prior[(size_t)g * MAXC + i] = 1.0f / (float)n;
+        if (lane == 0) p.value[g] = 0.0f;
+        return;
+    }
+    // SYNTH_COARSE: 2-bit weights and values from {-0.5, 0, 0, 0.5}: exact PUCT ties between SOME siblings, next to
+    // non-zero value sums (the hash evaluator's 24-bit priors never collide)
+    const bool coarse = p.evaluator == SYNTH_COARSE;
     unsigned long long sum = 0;
-    for (int i = lane; i < n; i += 64) sum += synth_weight(h, lm[i]);
+    for (int i = lane; i < n; i += 64) sum += coarse ? 1u + (synth_weight(h, lm[i]) >> 22) : synth_weight(h, lm[i]);
     sum = wave_sum_u64(sum);
     float fs = (float)sum;
-    for (int i = lane; i < n; i += 64) p.prior[(size_t)g * MAXC + i] = (float)synth_weight(h, lm[i]) / fs;
-    if (lane == 0) p.value[g] = synth_value(h);
+    for (int i = lane; i < n; i += 64)
+        p.prior[(size_t)g * MAXC + i] = (float)(coarse ? 1u + (synth_weight(h, lm[i]) >> 22) : synth_weight(h, lm[i])) / fs;
+    if (lane == 0) {
+        const float v = synth_value(h);
+        p.value[g] = coarse ? (v < -0.5f ? -0.5f : v >= 0.5f ? 0.5f : 0.0f) : v;
+    }
 }
 
 // ------------------------------------------------------------------ game (re)start
-__device__ inline void start_new_game(SpParams& p, int g, int lane) {
+// Game ordinal k (0-based on this handle) takes trace-ring row k % trace_cap.  The row may still belong to another game:
+// a LIVE one (a long game next to slots that cycle through short ones can be lapped: writing its rows would corrupt both
+// traces), or -- with trace_hold -- a finished one the host has not released yet (sc_selfplay_poll).  Then the slot
+// waits (ST_PENDING, its ordinal parked in game_id) and retries at every simulation step.
+__device__ inline void try_start_game(SpParams& p, int g, int lane, unsigned long long k) {
     GameCtl& c = p.ctl[g];
-    unsigned long long k = 0;
-    if (lane == 0) k = atomicAdd(&p.cnt->next_game, 1ULL);
-    k = __shfl(k, 0, 64);
-    if (k >= (unsigned long long)p.total_games) {
+    const int ts = (int)(k % (unsigned long long)p.trace_cap);
+    const int st = p.thdr[ts].state;
+    const bool busy = st == TR_LIVE || (p.trace_hold && st == TR_DONE);
+    if (busy) {
         if (lane == 0) {
-            c.status = ST_IDLE;
+            c.status = ST_PENDING;
             c.leaf_kind = LK_NONE;
+            c.game_id = p.first_game_id + k;
         }
         return;
     }
@@ -604,16 +658,31 @@ __device__ inline void start_new_game(SpParams& p, int g, int lane) {
         c.leaf_kind = LK_NONE;
         c.n_legal = 0;
         c.err = 0;
+        c.rollout_cur = p.rollout;
         c.game_id = p.first_game_id + k;
-        c.trace_slot = (int32_t)(k % (unsigned long long)p.trace_cap);
-        TraceHdr& th = p.thdr[c.trace_slot];
+        c.trace_slot = ts;
+        TraceHdr& th = p.thdr[ts];
         th.n_steps = 0;
         th.has_outcome = 0;
         th.termination = 0;
         th.winner = -1;
         th.game_id = c.game_id;
-        th.done = 0;
+        th.state = TR_LIVE;
     }
+}
+__device__ inline void start_new_game(SpParams& p, int g, int lane) {
+    GameCtl& c = p.ctl[g];
+    unsigned long long k = 0;
+    if (lane == 0) k = atomicAdd(&p.cnt->next_game, 1ULL);
+    k = __shfl(k, 0, 64);
+    if (k >= (unsigned long long)p.total_games) {
+        if (lane == 0) {
+            c.status = ST_IDLE;
+            c.leaf_kind = LK_NONE;
+        }
+        return;
+    }
+    try_start_game(p, g, lane, k);
 }
 __global__ __launch_bounds__(64) void k_init_slots(SpParams p) {
     const int g = blockIdx.x, lane = threadIdx.x;
@@ -621,7 +690,18 @@ __global__ __launch_bounds__(64) void k_init_slots(SpParams p) {
     for (int i = lane; i < 448; i += 64) b[i] = make_uint4(0, 0, 0, 0);
     if (lane < 8) p.meta[(size_t)g * 8 + lane] = 0;
     if (lane == 0) p.n_legal[g] = 0;
-    start_new_game(p, g, lane);
+    // slot g starts with game g (a deterministic slot <-> game map at start; later games are drawn from the counter as
+    // slots free up); no game has finished yet, so nothing else touches the counter during this launch
+    if (g == 0 && lane == 0)
+        atomicAdd(&p.cnt->next_game, (unsigned long long)(p.n_slots < p.total_games ? p.n_slots : p.total_games));
+    if (g >= p.total_games) {
+        if (lane == 0) {
+            p.ctl[g].status = ST_IDLE;
+            p.ctl[g].leaf_kind = LK_NONE;
+        }
+        return;
+    }
+    try_start_game(p, g, lane, (unsigned long long)g);
 }
 
 __device__ inline void finish_game(SpParams& p, int g, int lane, int has_outcome, int term, int winner) {
@@ -634,7 +714,7 @@ __device__ inline void finish_game(SpParams& p, int g, int lane, int has_outcome
         th.winner = winner;
         th.game_id = c.game_id;
         __threadfence();
-        th.done = 1;
+        th.state = TR_DONE;
         atomicAdd(&p.cnt->games_finished, 1);
         c.status = ST_FINISHED;
     }
@@ -753,6 +833,11 @@ __device__ __forceinline__ void dev_expand(SpParams& p, int g, int lane, Positio
     }
     cs_out = cs;
     cs_valid = true;
+    if (cs.status == ST_PENDING) {   // waiting for its trace-ring row (try_start_game)
+        try_start_game(p, g, lane, cs.game_id - p.first_game_id);
+        cs_valid = false;
+        return;
+    }
     if (cs.status != ST_ACTIVE || cs.leaf_kind == LK_NONE) return;
     const size_t nb = (size_t)g * p.node_cap;
     int32_t* N = p.N + nb;
@@ -836,7 +921,8 @@ __device__ __forceinline__ void dev_expand(SpParams& p, int g, int lane, Positio
     cs_out.sim = sim;
     cs_out.leaf_kind = LK_NONE;
     cs_out.err = cs.err | err;
-    if (sim < p.rollout) return;
+    const int budget = p.rollout_factor > 0.f ? cs.rollout_cur : p.rollout;
+    if (sim < budget) return;
     cs_valid = false;
 
     // ---------------- end of this ply's search (main.rs:198-233)
@@ -845,8 +931,9 @@ __device__ __forceinline__ void dev_expand(SpParams& p, int g, int lane, Positio
     const int ply = cs.ply;
     const NodeHdr h0 = H[0];
     const int nc = h0.nc, fc = h0.fc;
-    if (nc == 0) {
-        // mcts::step -> None: no children => no legal moves (main.rs:213-216)
+    if (nc == 0 || budget == 0) {
+        // mcts::step -> None: no children => no legal moves (main.rs:213-216), or a --rollout-factor budget of 0
+        // simulations (the reference then searches nothing and the root stays childless)
         HistChain hc{hist};
         int winner = -1;
         int term = outcome_claim_draw(hc, ply, &winner);
@@ -1029,6 +1116,7 @@ __global__ __launch_bounds__(64) void k_set_position(SpParams p, int g, const ui
         c.n_nodes = 1;
         c.n_exp = 1;
         c.leaf_kind = LK_NONE;
+        c.rollout_cur = p.rollout;
         c.status = ST_ACTIVE;
     }
 }

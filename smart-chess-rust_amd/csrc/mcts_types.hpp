@@ -7,7 +7,9 @@
 namespace sc {
 
 constexpr int MAXC = 224;  // SC_MAX_MOVES
-enum { ST_IDLE = 0, ST_ACTIVE = 1, ST_FINISHED = 2 };
+enum { ST_IDLE = 0, ST_ACTIVE = 1, ST_FINISHED = 2, ST_PENDING = 3 };   // PENDING: a game id is drawn, its trace-ring row is still in use
+enum { TR_FREE = 0, TR_LIVE = 1, TR_DONE = 2 };   // TraceHdr::state
+enum { SYNTH_HASH = 1, SYNTH_COARSE = 2, SYNTH_UNIFORM = 3 };   // SpParams::evaluator of the synthetic evaluators (sc_engine.h)
 enum { LK_NONE = 0, LK_EVAL = 1, LK_TERM_NEW = 2, LK_TERM_CACHED = 3 };
 enum { ERR_NONFINITE_UCT = 1, ERR_POOL_OVERFLOW = 2, ERR_BAD_MOVE_INDEX = 4, ERR_DEPTH_OVERFLOW = 8 };
 
@@ -19,7 +21,7 @@ struct GameCtl {
     int32_t trace_slot;
     uint64_t game_id;
     int32_t start_ply;  // ply index at which this slot's game started searching (sc_selfplay_set_position)
-    int32_t pad;
+    int32_t rollout_cur;  // --rollout-factor: this ply's simulation budget min(300, n_legal * factor) (src/main.rs:175-176)
 };
 
 // per-node header, fetched in one 8-byte load (and, for all children of a node, in the same round trip as their
@@ -33,7 +35,7 @@ struct NodeHdr {
 struct TraceHdr {
     int32_t n_steps, has_outcome, termination, winner;
     uint64_t game_id;
-    int32_t done, pad;
+    int32_t state, pad;   // TR_FREE / TR_LIVE / TR_DONE
 };
 
 struct Counters {
@@ -44,6 +46,8 @@ struct Counters {
 struct SpParams {
     int n_slots, rollout, num_steps, temp_switch, with_noise, outcome_gate, evaluator, external_noise;
     int tie_random;        // temperature 0: uniformly random child among the most visited (match play, src/play.rs:268-277)
+    int trace_hold;        // trace ring: a finished trace is kept until the host has released it (sc_selfplay_poll); 0: overwritten
+    float rollout_factor;  // > 0: per-ply budget min(300, n_legal * factor) instead of `rollout` (src/main.rs:175-176)
     uint64_t synth_salt;   // synthetic evaluator: second deterministic "player" (match tests)
     float cpuct, temperature, epsilon;
     uint64_t seed, first_game_id;

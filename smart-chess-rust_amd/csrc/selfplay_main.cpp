@@ -13,6 +13,8 @@
 // Extra flags (no reference counterpart): --games, --concurrency, --groups, --gpus, --seed, --blocks/--channels
 // (random-init network when no checkpoint is given), --first-game.
 // One host thread per GPU; games are sharded statically over GPUs, no collective.
+// Traces stream out: each game's file is written when the game ends (the reference saves at the end of its one game,
+// src/main.rs:235-238), from a bounded ring of traces on the device (sc_selfplay_poll), whatever --games is.
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -104,7 +106,6 @@ static int run_gpu(const Args& a, int gpu, int first, int count, int* finished_w
     }
     const int K = a.groups < 1 ? 1 : (a.groups > count ? count : a.groups);
     std::vector<sc_selfplay*> sps;
-    std::vector<int> counts;
     int rc = 0, off = 0;
     for (int k = 0; k < K && !rc; k++) {
         const int cnt = count / K + (k < count % K ? 1 : 0);
@@ -112,9 +113,10 @@ static int run_gpu(const Args& a, int gpu, int first, int count, int* finished_w
         const int slots = a.concurrency / K > 0 ? a.concurrency / K : 1;
         c.n_slots = cnt < slots ? cnt : slots;
         c.n_games = cnt;
-        // main.rs:175-180: --rollout-num, else 300 (the --rollout-factor form needs the per-position legal-move
-        // count on the host every ply; it is mapped to its cap of 300 here and reported)
+        // main.rs:175-180: --rollout-num N, or --rollout-factor F = min(300, n_legal * F) per ply (chosen on the device at
+        // the first simulation of each ply), or 300
         c.rollout_num = a.rollout_num > 0 ? a.rollout_num : 300;
+        c.rollout_factor = a.rollout_factor > 0 ? a.rollout_factor : 0.f;
         c.num_steps = a.num_steps;
         c.cpuct = a.cpuct;
         c.temperature = a.temperature;
@@ -126,6 +128,9 @@ static int run_gpu(const Args& a, int gpu, int first, int count, int* finished_w
         c.seed = a.seed;
         c.first_game_id = a.first_game + (unsigned long long)(first + off);
         c.own_stream = K > 1;
+        // bounded trace ring, drained as games end; a finished trace is held until its file is written
+        c.trace_capacity = 2 * c.n_slots + 64;
+        c.trace_hold = 1;
         sc_selfplay* sp = nullptr;
         if (sc_selfplay_create(eng, gpu, &c, &sp)) {
             fprintf(stderr, "gpu %d: %s\n", gpu, sc_last_error());
@@ -133,46 +138,56 @@ static int run_gpu(const Args& a, int gpu, int first, int count, int* finished_w
             break;
         }
         sps.push_back(sp);
-        counts.push_back(cnt);
         off += cnt;
     }
-    if (!rc && K == 1) {
-        rc = sc_selfplay_run(sps[0], 0);
-    } else if (!rc) {
-        // interleave the groups simulation step by simulation step until every game of every group is finished
-        const int chunk = a.rollout_num > 0 ? a.rollout_num : 300;
-        for (;;) {
-            rc = sc_selfplay_enqueue_interleaved(sps.data(), (int)sps.size(), chunk);
-            if (rc) break;
-            int active = 0;
-            for (sc_selfplay* sp : sps) {
-                sc_selfplay_stats st{};
-                rc |= sc_selfplay_get_stats(sp, &st);
-                active += st.games_active;
+    // interleave the groups simulation step by simulation step; after every chunk (one ply's worth of steps) write the
+    // traces of the games that have ended
+    int with_outcome = 0, finished = 0, errs = 0, written = 0;
+    long long sims = 0;
+    const int chunk = a.rollout_num > 0 ? a.rollout_num : 300;
+    std::vector<int32_t> fin(4096);
+    while (!rc) {
+        rc = sc_selfplay_enqueue_interleaved(sps.data(), (int)sps.size(), chunk);
+        if (rc) break;
+        int active = 0;
+        for (size_t k = 0; k < sps.size() && !rc; k++) {
+            sc_selfplay* sp = sps[k];
+            for (;;) {
+                const int n = sc_selfplay_poll(sp, fin.data(), (int)fin.size());
+                if (n < 0) {
+                    rc = 1;
+                    break;
+                }
+                for (int i = 0; i < n && !rc; i++) {
+                    sc_trace_info info{};
+                    if (sc_selfplay_get_trace(sp, fin[(size_t)i], &info, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr)) {
+                        rc = 1;
+                        break;
+                    }
+                    with_outcome += info.has_outcome;
+                    std::string path = trace_name(a, info.game_id + 1);
+                    if (sc_selfplay_write_trace_json(sp, fin[(size_t)i], path.c_str())) rc = 1;
+                    else written++;
+                }
+                if (n < (int)fin.size() || rc) break;
             }
-            if (rc || active == 0) break;
+            sc_selfplay_stats st{};
+            if (!rc && sc_selfplay_get_stats(sp, &st)) rc = 1;
+            active += st.games_active;
         }
+        if (rc || active == 0) break;
     }
     if (rc) fprintf(stderr, "gpu %d: %s\n", gpu, sc_last_error());
-    int with_outcome = 0, finished = 0, errs = 0;
-    long long sims = 0;
     for (size_t k = 0; k < sps.size(); k++) {
-        sc_selfplay* sp = sps[k];
         sc_selfplay_stats st{};
-        sc_selfplay_get_stats(sp, &st);
+        sc_selfplay_get_stats(sps[k], &st);
         finished += st.games_finished;
         sims += (long long)st.sims_done;
         errs |= st.error_flags;
-        for (int g = 0; g < counts[k] && !rc; g++) {
-            sc_trace_info info{};
-            if (sc_selfplay_get_trace(sp, g, &info, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr)) continue;
-            with_outcome += info.has_outcome;
-            std::string path = trace_name(a, info.game_id + 1);
-            if (sc_selfplay_write_trace_json(sp, g, path.c_str())) {
-                fprintf(stderr, "gpu %d: %s\n", gpu, sc_last_error());
-                rc = 1;
-            }
-        }
+    }
+    if (!rc && written != count) {
+        fprintf(stderr, "gpu %d: %d of %d traces written\n", gpu, written, count);
+        rc = 1;
     }
     printf("gpu %d: games %d finished %d with-outcome %d simulations %lld error_flags %d\n", gpu, count, finished, with_outcome, sims, errs);
     *finished_with_outcome = with_outcome;
@@ -185,7 +200,7 @@ int main(int argc, char** argv) {
     setenv("HIP_FORCE_DEV_KERNARG", "1", 0);   // kernel arguments in device memory; before any HIP call
     Args a;
     if (!parse(argc, argv, a)) return 2;
-    if (a.rollout_factor >= 0 && a.rollout_num > 0) {  // main.rs:74
+    if (a.rollout_factor != -1.f && a.rollout_num > 0) {  // main.rs:74
         fprintf(stderr, "both --rollout-factor and --rollout-num are specified.\n");
         return 2;
     }
@@ -194,7 +209,10 @@ int main(int argc, char** argv) {
                 a.device.c_str());
         return 2;
     }
-    if (a.rollout_factor >= 0) fprintf(stderr, "note: --rollout-factor is mapped to its cap (rollout 300, main.rs:176)\n");
+    if (a.rollout_factor != -1.f && !(a.rollout_factor > 0.f)) {
+        fprintf(stderr, "--rollout-factor must be positive\n");
+        return 2;
+    }
     int ndev = sc_device_count();
     if (ndev <= 0) {
         fprintf(stderr, "no MI355X visible\n");

@@ -14,6 +14,6 @@ There is NO CPU fallback: importing works anywhere (so the C ABI can be checked)
 compute entry point raises EngineError when the HIP library or a GPU is missing.
 """
 from .binding import (ChessHip, Engine, EngineError, Play, SelfPlay, encode_move, encode_positions, encode_steps, encode_steps_batch,  # noqa: F401
-                      enqueue_interleaved, elo, lib, lib_path, play_match, search,
+                      enqueue_interleaved, elo, find_max, lib, lib_path, play_match, runtime_flags, search,
                       move_uci, uci_move, write_trace_json, TERMINATION)
 from . import binding  # noqa: F401

@@ -15,6 +15,7 @@ MAX_MOVES = 224
 TERMINATION = {0: None, 1: "Checkmate", 2: "Stalemate", 3: "InsufficientMaterial", 4: "SeventyfiveMoves",
                5: "FivefoldRepetition", 6: "FiftyMoves", 7: "ThreefoldRepetition"}
 _WINNER = {1: "White", 0: "Black", -1: None}
+EVALUATORS = {"net": 0, "synth": 1, "synth_coarse": 2, "synth_uniform": 3}   # SC_EVAL_* (include/sc_engine.h)
 
 
 class EngineError(RuntimeError):
@@ -31,7 +32,7 @@ class SelfplayConfig(C.Structure):
                 ("epsilon", C.c_float), ("with_noise", C.c_int32), ("outcome_gate", C.c_int32),
                 ("evaluator", C.c_int32), ("external_noise", C.c_int32), ("seed", C.c_uint64),
                 ("first_game_id", C.c_uint64), ("trace_capacity", C.c_int32), ("own_stream", C.c_int32),
-                ("tie_random", C.c_int32)]
+                ("tie_random", C.c_int32), ("trace_hold", C.c_int32), ("rollout_factor", C.c_float)]
 
 
 class Stats(C.Structure):
@@ -49,6 +50,11 @@ _vp, _i, _i64, _u16p, _f = C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_float
 ABI = {
     "sc_last_error": (C.c_char_p, []),
     "sc_device_count": (_i, []),
+    "sc_runtime_flags": (_i, []),
+    "sc_last_warning": (C.c_char_p, []),
+    "sc_selfplay_poll": (_i, [_vp, _vp, _i]),
+    "sc_debug_find_max": (_i, [_i, _vp, _i, _vp]),
+    "sc_selfplay_debug_cycles": (_i, [_vp, _i, _vp]),
     "sc_engine_create": (_i, [C.POINTER(NetConfig), C.c_char_p, _i, C.POINTER(_vp)]),
     "sc_engine_destroy": (None, [_vp]),
     "sc_engine_max_batch": (_i, [_vp]),
@@ -447,13 +453,13 @@ class SelfPlay:
     def __init__(self, engine=None, n_slots=256, n_games=None, rollout_num=180, num_steps=150, cpuct=2.5,
                  temperature=0.0, temperature_switch=4, epsilon=0.15, with_noise=True, outcome_gate=100,
                  evaluator="net", external_noise=False, seed=0, first_game_id=0, trace_capacity=0, own_stream=False, device=0,
-                 tie_random=False):
+                 tie_random=False, trace_hold=False, rollout_factor=0.0):
         self.L = lib()
         self.engine = engine
         cfg = SelfplayConfig(n_slots, n_games if n_games is not None else n_slots, rollout_num, num_steps, cpuct,
                              temperature, temperature_switch, epsilon, int(with_noise), outcome_gate,
-                             0 if evaluator == "net" else 1, int(external_noise), seed, first_game_id, trace_capacity, int(own_stream),
-                             int(tie_random))
+                             EVALUATORS[evaluator], int(external_noise), seed, first_game_id, trace_capacity, int(own_stream),
+                             int(tie_random), int(trace_hold), float(rollout_factor))
         self.cfg = cfg
         h = C.c_void_p()
         _check(self.L.sc_selfplay_create(engine.h if engine else None, device, C.byref(cfg), C.byref(h)))
@@ -497,8 +503,17 @@ class SelfPlay:
         _check(self.L.sc_selfplay_timing(self.h, int(reset), C.byref(a), C.byref(b), C.byref(n)))
         return dict(ms_total=a.value, ms_tower_sum=b.value, tower_launches=n.value)
 
+    def poll(self, cap=4096):
+        """sc_selfplay_poll: handle-local indices of the games that finished since they were last reported"""
+        buf = np.zeros(max(cap, 1), np.int32)
+        n = self.L.sc_selfplay_poll(self.h, _p(buf), cap)
+        if n < 0:
+            _check(n)
+        return [int(x) for x in buf[:n]]
+
     def trace(self, game):
-        """-> dict in the reference's trace-file shape (src/trace.rs:5-9) or None if unfinished"""
+        """-> dict in the reference's trace-file shape (src/trace.rs:5-9); None if unfinished; raises EngineError when the
+        trace has left the device (ring row overwritten or released)"""
         info = TraceInfo()
         rc = self.L.sc_selfplay_get_trace(self.h, game, C.byref(info), None, None, None, None, None, None, None)
         if rc == 1:
@@ -559,6 +574,18 @@ class SelfPlay:
         if mv.size == 0:
             mv = np.zeros(1, np.uint16)
         _check(self.L.sc_selfplay_set_position(self.h, slot, _p(mv), len(moves)))
+
+
+def find_max(values, device=0):
+    """sc_debug_find_max: (one-round result or -2, four-round result) of the descent's arg-max on `values`"""
+    v = np.ascontiguousarray(values, np.float32)
+    out = np.zeros(2, np.int32)
+    _check(lib().sc_debug_find_max(device, _p(v), v.size, _p(out)))
+    return int(out[0]), int(out[1])
+
+
+def runtime_flags():
+    return int(lib().sc_runtime_flags())
 
 
 def enqueue_interleaved(handles, n_sims):

@@ -241,31 +241,9 @@ def test_root_noise_is_dirichlet(scamd):
 
 
 # ---------------------------------------------------------------------------------- full size (BASELINE cfg2)
-def test_full_size_invariants(scamd, orc):
-    """256 concurrent games, rollout 180, 10x256 bf16 net: invariants that do not need the oracle at size"""
+def test_short_complete_games_with_the_network(scamd, orc):
+    """(the 256-game full-size invariants live in test_gpu_parity2.py::test_full_size_search_invariants)"""
     eng = scamd.Engine(10, 256, seed=1)
-    R, G = 180, 256
-    sp = scamd.SelfPlay(eng, n_slots=G, n_games=100000, trace_capacity=2 * G, rollout_num=R, num_steps=150, cpuct=2.5, temperature=0.0,
-                        temperature_switch=4, epsilon=0.15, with_noise=True, seed=5)
-    sp.enqueue(R - 1)
-    sp.sync()
-    st = sp.stats()
-    assert st["error_flags"] == 0 and st["sims_done"] == G * (R - 1)
-    for g in (0, 97, 255):
-        t = sp.tree(g)
-        assert t["n"][0] == R - 1 and t["n_child"][0] == 20
-        kids = slice(t["first_child"][0], t["first_child"][0] + 20)
-        assert t["n"][kids].sum() == R - 2                          # first simulation only expands the root
-        assert 0.97 < t["prior"][kids].sum() <= 1.0 + 1e-6           # renormalised by (sum + 1e-5), chess.rs:891
-        assert np.isfinite(t["q"]).all() and np.abs(t["q"][0]) <= R
-        # every expanded node's children are contiguous and counted once
-        exp = np.nonzero(t["n_child"])[0]
-        assert t["n_child"][exp].sum() == len(t["n"]) - 1
-    sp.enqueue(2 * R + 1)                                           # finish ply 0 and two more plies
-    sp.sync()
-    assert all(sp.slot(g)["ply"] == 3 for g in (0, 128, 255))
-    assert sp.stats()["plies_done"] == 3 * G
-    sp.close()
     # short complete games: traces replay legally, children are the legal moves in order, visits add up
     sp = scamd.SelfPlay(eng, n_slots=64, n_games=64, rollout_num=32, num_steps=6, cpuct=2.5, with_noise=True, seed=6)
     sp.run()

@@ -1,0 +1,394 @@
+"""GPU parity tests, part 2 (-m gpu): the device code paths the first file never reached -- exact PUCT ties and the
+last-maximum rule (src/mcts.rs:78-88), nodes with more than 64 children (the four-round arg-max of the descent),
+BASELINE configs[1] and configs[3] at full size, the reference's 19/20-block goldens, --rollout-factor, the trace ring
+and the streaming drain.  Everything goes through the C ABI (include/sc_engine.h)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from helpers import random_games
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+RTOL = ATOL = 1e-2   # reference convention, scripts/eval_speed.py:40-43
+
+# 18 plies from the start position to a White-to-move position with 82 legal moves (found by a beam search on the
+# oracle's move generator, tools/find_wide_position.py): the root of a search from here has more than 64 children
+WIDE = ("e2e3 d7d5 d1g4 d8d6 f1b5 e8d8 b1c3 d6h2 c3d5 h2d6 h1h6 d6a3 b2b3 a3a4 c1b2 c7c5 b2e5 a4b3").split()
+MATED = ["f2f3", "e7e5", "g2g4", "d8h4"]   # White is checkmated: a game set to this line ends after its first search
+
+
+@pytest.fixture(scope="module")
+def scamd():
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "smart-chess-rust_amd"))
+    import scamd as m
+    if m.lib().sc_device_count() <= 0:
+        pytest.fail("no MI355X visible: the HIP path cannot be tested (and there is no fallback)")
+    return m
+
+
+def _same_tree(t, d):
+    return (len(t["n"]) == len(d["n"]) and np.array_equal(t["n"], d["n"]) and np.array_equal(t["q"], d["q"])
+            and np.array_equal(t["uct"], d["uct"]) and np.array_equal(t["move"][1:], d["move"][1:])
+            and np.array_equal(t["n_child"], d["n_child"]))
+
+
+def _pushed(orc, moves):
+    st = orc.State()
+    for m in moves:
+        st.push(m)
+    return st
+
+
+# ---------------------------------------------------------------------------------- find_max (a3)
+def test_find_max_device_forms(scamd):
+    """both arg-max forms of the descent on crafted values: Iterator::max_by keeps the LAST maximum"""
+    def last_max(u):
+        return max(i for i in range(len(u)) if u[i] == max(u))   # == on floats: -0.0 == +0.0, as PartialOrd compares
+
+    f = np.float32
+    cases = [[0.5] * 20, [0.5] * 64, [0.5] * 65, [0.5] * 218, [0.5] * 256, [1.0, 2.0, 2.0, 1.0], [-1.0, -3.0, -1.0, -2.0],
+             [f(0.0), f(-0.0)], [f(-0.0), f(0.0), f(-1.0)], [f(-0.0)] * 7 + [f(-2.0)], [3.0] + [1.0] * 63, [1.0] * 63 + [3.0],
+             [1.0] * 64 + [3.0] + [1.0] * 100, [1.0] * 130 + [3.0, 3.0] + [1.0] * 50, [3.0] + [1.0] * 200 + [3.0] + [2.0] * 10,
+             [-5.0] * 100 + [-4.0] + [-5.0] * 99 + [-4.0], [1e-30, 1e-30, 0.0], [-1e-30, -1e-30, -1.0],
+             [f(0.12625)] * 19 + [f(0.063125)]]
+    rnd = np.random.RandomState(5)
+    for n in (2, 17, 63, 64, 65, 127, 128, 129, 191, 192, 193, 218, 255, 256):
+        cases.append(list(rnd.randint(-3, 4, n).astype(np.float32) * f(0.25)))       # many exact ties, both signs
+        cases.append(list(rnd.standard_normal(n).astype(np.float32)))
+    for u in cases:
+        one, four = scamd.find_max(u)
+        want = last_max([float(x) for x in u])
+        assert four == want, (len(u), u[:8])
+        assert one == (want if len(u) <= 64 else -2), (len(u), u[:8])
+
+
+# ---------------------------------------------------------------------------------- ties in the search (a3, a5)
+@pytest.mark.parametrize("evaluator,oeval", [("synth_uniform", "orc_eval_synth_uniform"), ("synth_coarse", "orc_eval_synth_coarse")])
+@pytest.mark.parametrize("line", [[], WIDE], ids=["start20", "wide82"])
+def test_search_with_exact_ties_lockstep(scamd, orc, evaluator, oeval, line):
+    """uniform priors + value 0: every unvisited sibling ties and the device must descend into the LAST child, like
+    find_max (src/mcts.rs:78-88); coarse priors/values: ties between some siblings next to non-zero value sums.
+    Node pools, uct words and paths equal the oracle after every simulation -- with <= 64 and with > 64 children."""
+    R = 200
+    sp = scamd.SelfPlay(None, n_slots=1, n_games=1, rollout_num=R, num_steps=30, cpuct=2.5, with_noise=False, evaluator=evaluator, seed=3)
+    st = _pushed(orc, line)
+    n_root = len(st.legal_moves())
+    assert n_root == (82 if line else 20)
+    sp.set_position(0, line)
+    srch = orc.Search(st)
+    for s in range(R - 1):
+        sp.enqueue(1)
+        srch.sim(evaluator=oeval, cpuct=2.5, with_noise=False)
+        path = list(sp.slot(0)["path"])
+        assert path == list(srch.last_path()), s
+        if evaluator == "synth_uniform" and 1 <= s <= n_root:
+            assert path[1] == n_root + 1 - s, s           # children are visited last to first while they tie
+        if s % 5 == 0 or s > R - 4:
+            assert _same_tree(sp.tree(0), srch.dump()), s
+    t = sp.tree(0)
+    if evaluator == "synth_uniform":
+        u = t["uct"][1:1 + n_root]
+        assert (u == u.max()).sum() > 1                    # the last selection at the root still saw an exact tie
+    assert sp.stats()["error_flags"] == 0
+
+
+def test_search_wide_root_lockstep_exact(scamd, orc):
+    """> 64 legal moves: the four-round level of the descent (lane owns children lane, lane + 64, ...), the (value, index)
+    pair reduction and the header pick of the chosen child, against the oracle with the hash evaluator, with root noise"""
+    R = 180
+    sp = scamd.SelfPlay(None, n_slots=2, n_games=2, rollout_num=R, num_steps=40, cpuct=2.5, with_noise=True, epsilon=0.15,
+                        evaluator="synth", external_noise=True, seed=3)
+    st = _pushed(orc, WIDE)
+    sp.set_position(1, WIDE)
+    srch = orc.Search(st)
+    rnd = np.random.RandomState(1)
+    wide_levels = 0
+    for s in range(R - 1):
+        nz = rnd.dirichlet([0.3] * 82).astype(np.float32)
+        sp.set_noise(1, nz)
+        sp.enqueue(1)
+        srch.sim(cpuct=2.5, epsilon=0.15, with_noise=True, noise=nz.astype(np.float64))
+        assert list(sp.slot(1)["path"]) == list(srch.last_path()), s
+        if s % 9 == 0 or s > R - 4:
+            t, d = sp.tree(1), srch.dump()
+            assert _same_tree(t, d), s
+            wide_levels = int((d["n_child"] > 64).sum())
+    assert wide_levels >= 1 and sp.tree(1)["n_child"][0] == 82
+    # the chosen children of the wide root come from both rounds (index < 64 and >= 64)
+    kids = sp.tree(1)["n"][1:83]
+    assert kids[:64].sum() > 0 and kids[64:].sum() > 0
+    assert sp.stats()["error_flags"] == 0
+
+
+# ---------------------------------------------------------------------------------- network at full depth / width
+@pytest.mark.parametrize("nb", [19, 20])
+def test_network_matches_reference_goldens_deep(scamd, nb):
+    """the reference's default depth (19, py/module.py:110) and BASELINE configs[3] (20 blocks x 256): HIP forward against
+    vectors produced by the reference module itself (tools/gen_golden_nn.py)"""
+    g = np.load(os.path.join(GOLD, f"nn_ref_b{nb}_c256.npz"))
+    eng = scamd.Engine(nb, 256, seed=int(g["seed"]))
+    logp, val = eng.forward(g["boards"], g["meta"])
+    d = float(np.abs(logp - g["logp"]).max())
+    print(f"nb={nb} max|dlogp|={d:.4f} max|dvalue|={float(np.abs(val - g['value']).max()):.5f}")
+    np.testing.assert_allclose(logp, g["logp"], rtol=RTOL, atol=3 * ATOL)   # deeper stack: observed <= 0.02 at 20 blocks
+    np.testing.assert_allclose(val, g["value"], rtol=RTOL, atol=ATOL)
+    # priors of the legal moves (what the search consumes): total variation distance (validate_inference.py:22-23)
+    p_ref, p_hip = np.exp(g["logp"].astype(np.float64)), np.exp(logp.astype(np.float64))
+    assert (0.5 * np.abs(p_ref - p_hip).sum(axis=1)).max() < 1e-2
+    eng.close()
+
+
+def test_network_10x128_on_64_positions(scamd, orc):
+    """BASELINE configs[1]'s trunk (10 blocks x 128 channels; parity unpinned by the reference, which has no 128-wide
+    instantiation) against the oracle's bf16-emulating mode on 64 distinct positions: identical quantisation points,
+    only summation order differs.  Bounds = 2x the maxima observed on the MI355X (recorded in DESIGN.md section 7)."""
+    games = [g for g in random_games(orc, 90, 120, seed=21) if g[1].legal_moves()][:64]
+    boards = np.stack([g[1].encode()[0] for g in games])
+    meta = np.stack([g[1].encode()[1] for g in games])
+    assert len({b.tobytes() for b in boards}) >= 60
+    eng = scamd.Engine(10, 128, seed=9)
+    net = orc.Net(10, 128, seed=9, emulate_bf16=True)
+    logp, val = eng.forward(boards, meta)
+    dl, dv, dp = [], [], []
+    for k in range(64):
+        ol, ov = net.forward(boards[k], meta[k])
+        dl.append(np.abs(logp[k] - ol).max())
+        dv.append(abs(val[k] - ov))
+        dp.append(0.5 * np.abs(np.exp(logp[k].astype(np.float64)) - np.exp(ol.astype(np.float64))).sum())
+    print(f"10x128: max|dlogp|={max(dl):.4f} max|dvalue|={max(dv):.5f} max TVD={max(dp):.5f}")
+    assert max(dl) < 4e-2 and max(dv) < 4e-3 and max(dp) < 4e-3
+    eng.close()
+
+
+# ---------------------------------------------------------------------------------- full size (BASELINE cfg[1], cfg[3])
+@pytest.mark.parametrize("nb,C,R", [(10, 128, 180), (10, 256, 180), (20, 256, 800)], ids=["cfg1_10x128_r180", "ref_10x256_r180", "cfg3_20x256_r800"])
+def test_full_size_search_invariants(scamd, orc, nb, C, R):
+    """256 concurrent games at the BASELINE sizes: invariants that do not need the oracle at size.  configs[1] exactly
+    (256 slots, rollout 180, 10x128) and configs[3]'s per-GPU slice (256 slots, rollout 800, 20x256: node pools of
+    1 + 800*218 nodes per game, 802 tree positions)"""
+    eng = scamd.Engine(nb, C, seed=1)
+    G = 256
+    sp = scamd.SelfPlay(eng, n_slots=G, n_games=100000, trace_capacity=2 * G, rollout_num=R, num_steps=150, cpuct=2.5, temperature=0.0,
+                        temperature_switch=4, epsilon=0.15, with_noise=True, seed=5)
+    sp.enqueue(R - 1)
+    sp.sync()
+    st = sp.stats()
+    assert st["error_flags"] == 0 and st["sims_done"] == G * (R - 1) and st["nn_evals"] <= st["sims_done"]
+    for g in (0, 97, 255):
+        t = sp.tree(g)
+        assert t["n"][0] == R - 1 and t["n_child"][0] == 20
+        kids = slice(t["first_child"][0], t["first_child"][0] + 20)
+        assert t["n"][kids].sum() == R - 2                          # first simulation only expands the root
+        assert 0.97 < t["prior"][kids].sum() <= 1.0 + 1e-6           # renormalised by (sum + 1e-5), chess.rs:891
+        assert np.isfinite(t["q"]).all() and np.abs(t["q"][0]) <= R and np.isfinite(t["uct"]).all()
+        exp = np.nonzero(t["n_child"])[0]
+        assert t["n_child"][exp].sum() == len(t["n"]) - 1           # children contiguous, counted once
+        # visit counts are consistent down the tree: N(node) = 1 + sum N(children) for every expanded non-root node
+        for i in exp[1:][:50]:
+            fc, nc = t["first_child"][i], t["n_child"][i]
+            assert t["n"][i] == 1 + t["n"][fc:fc + nc].sum()
+        # every node's move is legal in its parent's position (replayed with the oracle along the most visited line)
+        s, i = orc.State(), 0
+        while t["n_child"][i] > 0:
+            fc, nc = t["first_child"][i], t["n_child"][i]
+            assert [int(m) for m in t["move"][fc:fc + nc]] == s.legal_moves()
+            j = fc + int(np.argmax(t["n"][fc:fc + nc]))
+            if t["n"][j] == 0:
+                break
+            s.push(int(t["move"][j]))
+            i = j
+    sp.enqueue(1)                                                   # the R-th simulation finishes ply 0
+    sp.sync()
+    assert all(sp.slot(g)["ply"] == 1 for g in (0, 128, 255)) and sp.stats()["plies_done"] == G
+    if R == 180:
+        sp.enqueue(R)
+        sp.sync()
+        assert sp.stats()["plies_done"] == 2 * G
+    assert sp.stats()["error_flags"] == 0
+    sp.close()
+    eng.close()
+
+
+# ---------------------------------------------------------------------------------- --rollout-factor
+def test_rollout_factor_games_exact(scamd, orc):
+    """-r/--rollout-factor (src/main.rs:175-176): per-ply budget min(300, n_legal * factor), chosen on the device at the
+    first simulation of the ply; whole games equal the oracle's"""
+    cfg = dict(num_steps=30, cpuct=2.5, temperature=0.0, temperature_switch=4, with_noise=False)
+    for factor in (1.5, 0.26, 20.0):
+        sp = scamd.SelfPlay(None, n_slots=3, n_games=5, rollout_num=300, rollout_factor=factor, evaluator="synth", seed=17,
+                            outcome_gate=100, **cfg)
+        sp.run()
+        assert sp.stats()["error_flags"] == 0 and sp.stats()["games_finished"] == 5
+        for gi in range(5):
+            tr = sp.trace(gi)
+            ref = orc.selfplay_game(rollout_num=300, rollout_factor=factor, seed=17, game_id=tr["game_id"], outcome_gate=100, **cfg)
+            assert tr["steps"] == ref["steps"] and tr["outcome"] == ref["outcome"], (factor, gi)
+        budgets = {sum(c[1] for c in s[2]) + 1 for s in sp.trace(0)["steps"]}
+        assert (budgets == {300}) if factor == 20.0 else (len(budgets) > 1 and max(budgets) < 300)
+        sp.close()
+    with pytest.raises(scamd.EngineError):
+        scamd.SelfPlay(None, n_slots=1, rollout_num=100, rollout_factor=2.0, evaluator="synth")
+
+
+# ---------------------------------------------------------------------------------- trace ring / streaming drain
+def _lap(sp, rounds, R):
+    """slot 1 burns through game ids (each is set to a mated position and ends after one search) while slot 0 plays on"""
+    for _ in range(rounds):
+        if sp.slot(1)["status"] == 1:
+            sp.set_position(1, MATED)
+        sp.enqueue(R)
+        sp.sync()
+
+
+def test_trace_ring_never_hands_a_live_row_to_a_new_game(scamd, orc):
+    """ring of 4 rows, 2 slots: slot 0 plays a 12-ply game (row 0) while slot 1 finishes games 1, 2, 3 at once; game 4
+    maps to row 0 again and has to WAIT for game 0 (it used to overwrite the live trace).  With trace_hold every trace
+    stays until the host has read it: game 0's trace equals the oracle's, bit for bit."""
+    R = 8
+    cfg = dict(rollout_num=R, num_steps=12, cpuct=2.5, temperature=0.0, temperature_switch=2, with_noise=False)
+    sp = scamd.SelfPlay(None, n_slots=2, n_games=9, evaluator="synth", seed=4, outcome_gate=100, trace_capacity=4, trace_hold=True, **cfg)
+    _lap(sp, 4, R)
+    s1 = sp.slot(1)
+    assert s1["status"] == 3 and s1["game_id"] == 4                   # ST_PENDING: waiting for row 0
+    got = {}
+    first = sp.poll()
+    assert sorted(first) == [1, 2, 3]
+    for g in first:
+        tr = sp.trace(g)
+        assert tr["steps"] == [] and tr["outcome"] == {"termination": "Checkmate", "winner": "Black"}
+        got[g] = tr
+    assert sp.trace(0) is None                                        # still being played
+    with pytest.raises(scamd.EngineError):
+        sp.run()                                                      # a held ring smaller than n_games needs the poll loop
+    for _ in range(200):
+        sp.enqueue(R)
+        for g in sp.poll():
+            assert g not in got
+            got[g] = sp.trace(g)
+        if len(got) == 9:
+            break
+    assert sorted(got) == list(range(9)) and sp.stats()["games_finished"] == 9 and sp.stats()["error_flags"] == 0
+    for g in (0, 4, 5, 6, 7, 8):
+        ref = orc.selfplay_game(seed=4, game_id=g, outcome_gate=100, **cfg)
+        assert got[g]["steps"] == ref["steps"] and got[g]["outcome"] == ref["outcome"], g
+    sp.poll()                                                         # releases the last batch
+    with pytest.raises(scamd.EngineError, match="released|overwritten"):
+        sp.trace(0)
+    sp.close()
+    # without trace_hold a finished trace may be overwritten -- but never a live one: game 4 still waits for game 0,
+    # then takes its row; asking for game 0 afterwards is answered with the distinct "overwritten" code
+    sp = scamd.SelfPlay(None, n_slots=2, n_games=9, evaluator="synth", seed=4, outcome_gate=100, trace_capacity=4, **cfg)
+    _lap(sp, 4, R)
+    assert sp.slot(1)["status"] == 3 and sp.trace(0) is None
+    sp.run()
+    assert sp.stats()["games_finished"] == 9 and sp.stats()["error_flags"] == 0
+    with pytest.raises(scamd.EngineError, match="overwritten"):
+        sp.trace(0)
+    for g in (5, 6, 7, 8):
+        tr = sp.trace(g)
+        ref = orc.selfplay_game(seed=4, game_id=g, outcome_gate=100, **cfg)
+        assert tr["steps"] == ref["steps"] and tr["game_id"] == g
+    sp.close()
+
+
+def test_poll_streams_every_game_once(scamd, orc):
+    """sc_selfplay_poll on a bounded ring with many more games than rows: every game is reported exactly once, in time to
+    be read, and equals the oracle's game"""
+    cfg = dict(rollout_num=6, num_steps=5, cpuct=2.5, temperature=1.0, temperature_switch=100, with_noise=False)
+    sp = scamd.SelfPlay(None, n_slots=6, n_games=100, evaluator="synth", seed=9, first_game_id=1000, trace_capacity=12, trace_hold=True, **cfg)
+    seen = {}
+    for _ in range(400):
+        sp.enqueue(6)
+        for g in sp.poll(cap=5):                                      # a small cap: the rest is reported by later polls
+            assert g not in seen
+            seen[g] = sp.trace(g)
+        if len(seen) == 100:
+            break
+    assert sorted(seen) == list(range(100))
+    for g in (0, 37, 99):
+        ref = orc.selfplay_game(seed=9, game_id=1000 + g, **cfg)
+        assert seen[g]["steps"] == ref["steps"] and seen[g]["game_id"] == 1000 + g
+    sp.close()
+
+
+# ---------------------------------------------------------------------------------- multi-GPU readiness (8e)
+def test_disjoint_handles_stand_in_for_ranks(scamd, tmp_path):
+    """games shard by id: two handles with disjoint first_game_id ranges -- what two ranks / two GPUs run --
+    produce, together, byte-identical trace files to one handle playing all games; `sc-selfplay --gpus <device_count>`
+    writes the same files (on the one-GPU box this is the single-device path of the same launcher code)"""
+    import subprocess
+    cfg = dict(rollout_num=16, num_steps=8, cpuct=2.0, temperature=0.0, temperature_switch=2, epsilon=0.15, with_noise=True, seed=11)
+    eng = scamd.Engine(1, 128, seed=11)
+    one = scamd.SelfPlay(eng, n_slots=8, n_games=8, **cfg)
+    one.run()
+    a = scamd.SelfPlay(eng, n_slots=4, n_games=4, first_game_id=0, own_stream=True, **cfg)
+    b = scamd.SelfPlay(eng, n_slots=4, n_games=4, first_game_id=4, own_stream=True, **cfg)
+    for _ in range(8):
+        scamd.enqueue_interleaved([a, b], 16)
+    d1, d2, d3 = tmp_path / "one", tmp_path / "two", tmp_path / "cli"
+    for d in (d1, d2, d3):
+        d.mkdir()
+    ids = set()
+    for g in range(8):
+        one.write_trace(g, str(d1 / f"trace{g + 1}.json"))
+    for h in (a, b):
+        for g in range(4):
+            gid = h.trace(g)["game_id"]
+            ids.add(gid)
+            h.write_trace(g, str(d2 / f"trace{gid + 1}.json"))
+    assert ids == set(range(8))
+    ndev = scamd.lib().sc_device_count()
+    cli = os.path.join(ROOT, "smart-chess-rust_amd", "lib", "sc-selfplay")
+    r = subprocess.run([cli, "-d", "cuda", "--rollout-num", "16", "-n", "8", "--temperature", "0", "--cpuct", "2", "--temperature-switch", "2",
+                        "--games", "8", "--concurrency", "8", "--blocks", "1", "--channels", "128", "--seed", "11", "--gpus", str(ndev),
+                        "-t", str(d3 / "trace{}.json")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    for k in range(1, 9):
+        ref = open(str(d1 / f"trace{k}.json")).read()
+        assert open(str(d2 / f"trace{k}.json")).read() == ref, k
+        assert open(str(d3 / f"trace{k}.json")).read() == ref, k
+    for h in (one, a, b):
+        h.close()
+    eng.close()
+
+
+def test_cli_rollout_factor_and_streaming(tmp_path, orc):
+    """sc-selfplay -r F: the per-ply budget follows the root's legal-move count; more games than ring rows stream out"""
+    import subprocess
+    cli = os.path.join(ROOT, "smart-chess-rust_amd", "lib", "sc-selfplay")
+    r = subprocess.run([cli, "-d", "cuda", "-r", "1.5", "-n", "4", "--temperature", "0", "--cpuct", "2", "--temperature-switch", "1",
+                        "--games", "70", "--concurrency", "2", "--blocks", "1", "--channels", "128", "--seed", "5",
+                        "-t", str(tmp_path / "trace{}.json")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    for k in range(1, 71):      # ring = 2*2 + 64 rows < 70 games
+        js = json.load(open(str(tmp_path / f"trace{k}.json")))
+        st = orc.State()
+        assert len(js["steps"]) == 4
+        for mv, q, kids in js["steps"]:
+            n = len(st.legal_moves())
+            assert [c[0] for c in kids] == st.legal_uci() and sum(c[1] for c in kids) == min(300, int(np.float32(n) * np.float32(1.5))) - 1
+            st.push(mv)
+
+
+def test_encode_positions_rows_are_zero_past_n_legal(scamd):
+    """the legal-move tables come back zero-filled past n_legal for every batch size (the two tables are separate regions
+    of a padded arena)"""
+    eng = scamd.Engine(0, 128, seed=1)
+    import ctypes as C
+    L = scamd.lib()
+    for n in (3, 1, 2):
+        off = np.zeros(n + 1, np.uint32)
+        flat = np.zeros(1, np.uint16)
+        lm = np.full((n, 224), 0xFFFF, np.uint16)
+        li = np.full((n, 224), 0xFFFF, np.uint16)
+        nl = np.zeros(n, np.int32)
+        rc = L.sc_encode_positions(eng.h, 0, n, flat.ctypes.data_as(C.c_void_p), off.ctypes.data_as(C.c_void_p), None, None,
+                                   lm.ctypes.data_as(C.c_void_p), li.ctypes.data_as(C.c_void_p), nl.ctypes.data_as(C.c_void_p), None)
+        assert rc == 0 and (nl == 20).all()
+        assert (lm[:, 20:] == 0).all() and (li[:, 20:] == 0).all() and (lm[:, :20] != 0).all()
+    eng.close()

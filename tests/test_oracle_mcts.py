@@ -50,7 +50,50 @@ def test_uct_arithmetic_and_invariants(orc):
     want = np.array([_uct_np(0.0, pri[i], 0.0, 0, False, 2.5) for i in range(20)], np.float32)
     assert np.array_equal(d2["uct"][1:21], want)
     chosen = int(np.nonzero(d2["n"][1:21])[0][0])
-    assert chosen == max(i for i in range(20) if want[i] == want.max())
+    assert chosen == int(np.argmax(want))            # the hash evaluator's priors never collide: no tie here (see below)
+
+
+def test_find_max_keeps_the_last_maximum(orc):
+    """find_max = Iterator::max_by (src/mcts.rs:78-88): of equal PUCT values the LAST child wins.  Hand-computed on the
+    uniform test evaluator (prior 1/20 for every root move, value 0):
+      sim 1 expands the root; sim 2: all 20 children have u = (0 + 0.01) / 1 * 2.5 * 0.05 -> child 19 (node 20);
+      sim 3: child 19 has N = 1, u = (1 + 0.01) / 2 * 2.5 * 0.05 < the others' (1 + 0.01) / 1 * 2.5 * 0.05 -> child 18;
+      ... sims 2..21 visit the children in the order 19, 18, .., 0; sim 22: all N = 1 tie again -> child 19, and below it
+      the last of ITS children."""
+    f = np.float32
+    s = orc.Search(orc.State())
+    s.sim(evaluator="orc_eval_synth_uniform", cpuct=2.5)
+    assert list(s.last_path()) == [0]
+    for k in range(2, 22):
+        s.sim(evaluator="orc_eval_synth_uniform", cpuct=2.5)
+        assert list(s.last_path()) == [0, 22 - k], k
+        d = s.dump()
+        tot = f(np.sqrt(f(k - 2)))
+        u_unvisited = f(f(f(tot + f(0.01)) / f(1)) * f(2.5)) * f(f(1) / f(20))
+        assert d["uct"][22 - k] == u_unvisited                       # value written at selection time
+    s.sim(evaluator="orc_eval_synth_uniform", cpuct=2.5)
+    d = s.dump()
+    fc, nc = int(d["first_child"][20]), int(d["n_child"][20])
+    assert nc > 1 and list(s.last_path()) == [0, 20, fc + nc - 1]
+    assert np.all(d["uct"][1:21] == d["uct"][1])                     # an exact 20-way tie, resolved to the last
+    # coarse evaluator: ties between SOME siblings (equal 2-bit weights) next to non-zero value sums
+    c = orc.Search(orc.State())
+    for _ in range(2):
+        c.sim(evaluator="orc_eval_synth_coarse", cpuct=2.5)
+    d = c.dump()
+    u = d["uct"][1:21]
+    assert (u == u.max()).sum() > 1 and int(c.last_path()[1]) - 1 == max(i for i in range(20) if u[i] == u.max())
+
+
+def test_rollout_factor_budget(orc):
+    """--rollout-factor (src/main.rs:175-176): min(300, (n_legal as f32 * v) as i32) simulations per ply"""
+    g = orc.selfplay_game(rollout_num=300, num_steps=6, with_noise=False, seed=2, rollout_factor=1.5)
+    st = orc.State()
+    for mv, q, kids in g["steps"]:
+        n = len(st.legal_moves())
+        assert len(kids) == n and sum(k[1] for k in kids) == min(300, int(np.float32(n) * np.float32(1.5))) - 1
+        st.push(mv)
+    assert orc.selfplay_game(rollout_num=300, num_steps=2, with_noise=False, seed=2, rollout_factor=40.0)["n_sims"] == 600
 
 
 def test_choose_child_rules(orc):

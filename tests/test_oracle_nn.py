@@ -11,10 +11,11 @@ import scw
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
 
-@pytest.mark.parametrize("nb", [1, 10])
+@pytest.mark.parametrize("nb", [1, 10, 19, 20])
 def test_oracle_matches_reference_module(orc, nb):
+    """19 = the reference's default depth (py/module.py:110); 20 = BASELINE configs[3]"""
     g = np.load(os.path.join(GOLD, f"nn_ref_b{nb}_c256.npz"))
-    assert int(g["n_params"]) == {1: 3755740, 10: 14979676}[nb]
+    assert int(g["n_params"]) == {1: 3755740, 10: 14979676, 19: 26203612, 20: 27450716}[nb]      # SURVEY.md section 8 row a19
     net = orc.Net(nb, 256, seed=int(g["seed"]))
     for k in range(len(g["names"])):
         logp, v = net.forward(g["boards"][k], g["meta"][k])

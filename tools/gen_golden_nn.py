@@ -100,7 +100,10 @@ def main():
     metas = np.stack(metas)
 
     out_dir = os.path.join(ROOT, "tests", "golden")
-    for n_blocks in (1, 10):
+    # 19 = the reference's default depth (py/module.py:110), 20 = BASELINE configs[3]; existing files are kept unless --force
+    for n_blocks in (1, 10, 19, 20):
+        if os.path.exists(os.path.join(out_dir, f"nn_ref_b{n_blocks}_c256.npz")) and "--force" not in sys.argv:
+            continue
         model = refmod.load_model(n_res_blocks=n_blocks, device="cpu", compile=False, inference=True)
         sd = model.state_dict()
         table = scw.tensor_table(n_blocks, 256)
