@@ -35,13 +35,16 @@ PEAK_BF16_TFLOPS = 2500.0  # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md, c
 HBM_PEAK_GBS = 8000.0
 
 
-def macs_per_position(n_blocks, C):
-    """MACs of one forward of one position (BASELINE.md section 2 / SURVEY.md section 8d)."""
+def macs_per_position(n_blocks, C, tower_only=False):
+    """MACs of one forward of one position (BASELINE.md section 2 / SURVEY.md section 8d).  tower_only: without the value
+    head's two Linear layers, which run in k_value_fc1 / the search kernel's fused tail, not in the tower launch that the
+    roofline figure times."""
     H = 256
     stem = 64 * 112 * 9 * C
     block = 2 * 64 * C * 9 * C + 2 * C * (C // 2)
     policy = 64 * C * H + 64 * H * 73
-    value = 64 * C * H + (64 * H + 7) * 128 + 128
+    value_fc = (64 * H + 7) * 128 + 128
+    value = 64 * C * H + (0 if tower_only else value_fc)
     return stem + n_blocks * block + policy + value
 
 
@@ -58,8 +61,11 @@ def cpu_baseline(n_blocks, C, budget_s, rollout):
     from oracle import oracle_py as orc
 
     orc.build()
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    cores = max(1, min(cores, 16))
+    # every core this process may run on (the reference's convention is one single-threaded game per core,
+    # dockerfile:14 OMP_NUM_THREADS=1 + scripts/run_batch's `parallel -j`)
+    total_cores = os.cpu_count() or 1
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else total_cores
+    cores = max(1, cores)
     net = orc.Net(n_blocks, C, seed=1)
     ev = orc.eval_fn("orc_eval_net")
 
@@ -94,6 +100,7 @@ def cpu_baseline(n_blocks, C, budget_s, rollout):
         "value": round(out["faithful"][0], 2),
         "unit": "simulations/s",
         "cores": cores,
+        "cores_total": total_cores,
         "kind": "port",
         "sample": (f"{cores} self-play games from the start position (one per core, 1 thread each, rollout={rollout} per ply) "
                    f"for {out['faithful'][2]:.1f} s wall, fp32 {n_blocks}x{C} net re-evaluated at every path node "
@@ -113,7 +120,8 @@ def run_gpu(args, rank, world, local_rank):
     # the other group's network launch -- what a 512-games-per-GPU deployment gets from the same kernels)
     runs = [("main", args.channels, args.games, max(1, args.groups))]
     if args.alt and world == 1:
-        runs += [("alt", 256 if args.channels == 128 else 128, args.games, max(1, args.groups)), ("x2", args.channels, 2 * args.games, 2)]
+        runs += [("steady", args.channels, args.games, 1),
+                 ("alt", 256 if args.channels == 128 else 128, args.games, max(1, args.groups)), ("x2", args.channels, 2 * args.games, 2)]
     for tag, C, G, K in runs:
         eng = scamd.Engine(args.blocks, C, seed=1, device=local_rank)
         assert G % K == 0
@@ -136,34 +144,61 @@ def run_gpu(args, rank, world, local_rank):
             return tot
 
         steps = args.steps if tag == "main" else max(2, args.steps // 4)
+        if tag == "steady":
+            seed_mid_game_positions(scamd, eng, sps[0], G, R)
         enqueue(args.warmup * R)
-        s0 = stats()
         for sp in sps:
             sp.enable_timing(args.timing_stride)
             sp.timing(reset=True)
-        for sp in sps:
-            sp.sync()
-        cuda_sync()
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            enqueue(R)
-        for sp in sps:
-            sp.sync()
-        cuda_sync()
-        t1 = time.perf_counter()
-        barrier()
+        # `repeats` timed regions of exactly `steps` plies each, every one bracketed by barrier + synchronise on both sides;
+        # the reported region is the median one (median of 3)
+        regions = []
+        nn0 = stats()
+        for _ in range(args.repeats if tag == "main" else 1):
+            s0 = stats()
+            for sp in sps:
+                sp.sync()
+            cuda_sync()
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                enqueue(R)
+            for sp in sps:
+                sp.sync()
+            cuda_sync()
+            t1 = time.perf_counter()
+            barrier()
+            s1 = stats()
+            regions.append((t1 - t0, s1["sims_done"] - s0["sims_done"]))
         tms = [sp.timing() for sp in sps]
         s1 = stats()
         nl = sum(t["tower_launches"] for t in tms)
-        res[tag] = dict(C=C, seconds=t1 - t0, steps=steps, sims=s1["sims_done"] - s0["sims_done"],
-                        nn_evals=s1["nn_evals"] - s0["nn_evals"], err=s1["error_flags"],
+        res[tag] = dict(C=C, regions=regions, steps=steps, nn_evals=s1["nn_evals"] - nn0["nn_evals"],
+                        sims_all=s1["sims_done"] - nn0["sims_done"], err=s1["error_flags"],
                         tower_ms=sum(t["ms_tower_sum"] for t in tms) / max(nl, 1), tower_launches=nl,
                         span_ms=max(t["ms_total"] for t in tms), groups=K, games=G)
+        if tag == "steady":
+            plies = [sps[0].slot(g)["ply"] for g in range(0, G, 8)]
+            res[tag]["ply_min_max"] = (min(plies), max(plies))
         for sp in sps:
             sp.close()
         eng.close()
     return res
+
+
+def seed_mid_game_positions(scamd, eng, sp, G, R):
+    """Steady-state stand-in: a self-play node does not march 256 games in lockstep from the start position -- its slots
+    hold games at every stage.  A few quick games (rollout 16) are played to 150 plies with the same network, and slot g
+    of the measured handle starts from the first g*150/G moves of one of them: plies 0..149 are spread evenly over the
+    slots (deeper histories, mid-game branching factors, repetition planes set)."""
+    quick = scamd.SelfPlay(eng, n_slots=8, n_games=8, rollout_num=16, num_steps=150, cpuct=2.5, temperature=0.0,
+                           temperature_switch=8, epsilon=0.15, with_noise=True, seed=77, outcome_gate=10 ** 6)
+    quick.run()
+    lines = [[s[0] for s in quick.trace(g)["steps"]] for g in range(8)]
+    quick.close()
+    for g in range(G):
+        line = lines[g % 8]
+        sp.set_position(g, line[:min(len(line), (g * 150) // G)])
 
 
 _dist = None
@@ -189,6 +224,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--repeats", type=int, default=3, help="timed regions of --steps plies each; the median one is reported")
     ap.add_argument("--games", type=int, default=256, help="concurrent games per GPU")
     ap.add_argument("--rollout", type=int, default=180)
     ap.add_argument("--blocks", type=int, default=10)
@@ -236,31 +272,45 @@ def main():
 
     if args.cpu_dry_run:
         from oracle import oracle_py as orc
-        barrier()
-        t0 = time.perf_counter()
-        sims = 0
-        for k in range(args.steps):
-            g = orc.selfplay_game(rollout_num=8, num_steps=2, seed=1234, game_id=shard(10 ** 7, rank) + k)
-            sims += g["n_sims"]
-        t1 = time.perf_counter()
-        barrier()
-        res = {"main": dict(C=args.channels, seconds=t1 - t0, steps=args.steps, sims=sims, nn_evals=0, err=0, tower_ms=0.0,
-                            tower_launches=0, span_ms=0.0)}
+        regions = []
+        for rep_i in range(args.repeats):
+            barrier()
+            t0 = time.perf_counter()
+            sims = 0
+            for k in range(args.steps):
+                g = orc.selfplay_game(rollout_num=8, num_steps=2, seed=1234, game_id=shard(10 ** 7, rank) + rep_i * args.steps + k)
+                sims += g["n_sims"]
+            t1 = time.perf_counter()
+            barrier()
+            regions.append((t1 - t0, sims))
+        res = {"main": dict(C=args.channels, regions=regions, steps=args.steps, nn_evals=0, sims_all=sum(r[1] for r in regions), err=0,
+                            tower_ms=0.0, tower_launches=0, span_ms=0.0)}
     else:
         res = run_gpu(args, rank, world, local_rank)
 
     m = res["main"]
-    seconds, sims = m["seconds"], float(m["sims"])
+    # per region: MAX of the time over ranks, SUM of the simulations; the median region (by throughput) is reported
+    secs = [r[0] for r in m["regions"]]
+    simc = [float(r[1]) for r in m["regions"]]
     if world > 1:
-        t = torch.tensor([seconds], dtype=torch.float64)
-        s = torch.tensor([sims], dtype=torch.float64)
+        t = torch.tensor(secs, dtype=torch.float64)
+        sv = torch.tensor(simc, dtype=torch.float64)
         if not args.cpu_dry_run:
-            t, s = t.cuda(), s.cuda()
+            t, sv = t.cuda(), sv.cuda()
         _dist.all_reduce(t, op=_dist.ReduceOp.MAX)   # timing only -- no collective on the data path
-        _dist.all_reduce(s, op=_dist.ReduceOp.SUM)
-        seconds, sims = float(t.item()), float(s.item())
+        _dist.all_reduce(sv, op=_dist.ReduceOp.SUM)
+        secs, simc = [float(x) for x in t.tolist()], [float(x) for x in sv.tolist()]
+    rates = [n / t_ for n, t_ in zip(simc, secs)]
+    mid = sorted(range(len(rates)), key=lambda i: rates[i])[len(rates) // 2]
+    seconds, sims = secs[mid], simc[mid]
+
+    def rate(r):
+        t_, n_ = r["regions"][0]
+        return n_ / t_, 1e3 * t_ / r["steps"]
+
     if rank == 0:
         flop_pos = 2.0 * macs_per_position(args.blocks, m["C"])
+        flop_tower = 2.0 * macs_per_position(args.blocks, m["C"], tower_only=True)
         out = {
             # BASELINE.json's metric string, verbatim, for the configuration it is quoted on
             "metric": ("MCTS simulations/sec (whole node), self-play rollout=180, at 1/2/4/8 MI355X" if args.rollout == 180
@@ -283,32 +333,41 @@ def main():
                 "games_per_gpu": args.games, "rollout": args.rollout, "net": f"{args.blocks}x{m['C']}",
                 "step": "one ply = rollout simulation steps over all games", "parallelism": f"games sharded over {world} GPU(s), no collective",
             },
+            "repeats": {"regions": len(rates), "reported": "median", "values": [round(x, 1) for x in rates]},
         }
         if not args.cpu_dry_run:
             pos_per_launch = args.games // m.get("groups", 1)
-            tf = pos_per_launch * flop_pos / (m["tower_ms"] * 1e-3) / 1e12 if m["tower_ms"] > 0 else 0.0
+            tf = pos_per_launch * flop_tower / (m["tower_ms"] * 1e-3) / 1e12 if m["tower_ms"] > 0 else 0.0
             out["roofline"] = {
                 "bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(tf / PEAK_BF16_TFLOPS, 4), "traffic": load_traffic(m["C"]),
                 "kernel": f"k_tower32<{m['C']}>", "avg_launch_ms": round(m["tower_ms"], 4), "launches_timed": m["tower_launches"],
-                "flop_per_launch": pos_per_launch * flop_pos, "positions_per_launch": pos_per_launch, "concurrent_groups": m.get("groups", 1),
+                "flop_per_launch": pos_per_launch * flop_tower, "positions_per_launch": pos_per_launch, "concurrent_groups": m.get("groups", 1),
+                "flop_note": "the tower launch's own layers (stem, blocks, head convs); value_head.ffn runs in k_value_fc1 / the search kernel",
                 "end_to_end_frac": round(sims / seconds / world * flop_pos / (PEAK_BF16_TFLOPS * 1e12), 4),
             }
-            out["nn_evals_per_sim"] = round(m["nn_evals"] / max(m["sims"], 1), 4)
+            out["nn_evals_per_sim"] = round(m["nn_evals"] / max(m["sims_all"], 1), 4)
             out["error_flags"] = m["err"]
+            if "steady" in res:
+                st = res["steady"]
+                v, ms = rate(st)
+                out["also_steady"] = {"value": round(v, 1), "ms_per_step": round(ms, 3), "plies_min_max": list(st["ply_min_max"]),
+                                      "nn_evals_per_sim": round(st["nn_evals"] / max(st["sims_all"], 1), 4), "error_flags": st["err"],
+                                      "note": ("same configuration, but the slots hold games at every stage: slot g starts from the first "
+                                               "g*150/G plies of a pre-played game (mid-game branching factors, full 8-board histories)")}
             if "alt" in res:
                 a = res["alt"]
-                fa = 2.0 * macs_per_position(args.blocks, a["C"])
-                out["also"] = {"net": f"{args.blocks}x{a['C']}", "value": round(a["sims"] / a["seconds"], 1),
-                               "ms_per_step": round(1e3 * a["seconds"] / a["steps"], 3),
+                fa = 2.0 * macs_per_position(args.blocks, a["C"], tower_only=True)
+                v, ms = rate(a)
+                out["also"] = {"net": f"{args.blocks}x{a['C']}", "value": round(v, 1), "ms_per_step": round(ms, 3),
                                "tower_avg_ms": round(a["tower_ms"], 4),
                                "roofline_frac": round(args.games * fa / (a["tower_ms"] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4)
                                if a["tower_ms"] > 0 else None}
             if "x2" in res:
                 x = res["x2"]
+                v, ms = rate(x)
                 out["also_2x_games"] = {"games_per_gpu": x["games"], "groups": x["groups"], "net": f"{args.blocks}x{x['C']}",
-                                        "value": round(x["sims"] / x["seconds"], 1),
-                                        "ms_per_step": round(1e3 * x["seconds"] / x["steps"], 3),
+                                        "value": round(v, 1), "ms_per_step": round(ms, 3),
                                         "note": "two interleaved groups of games on two HIP streams; not the BASELINE configuration"}
             if world == 1 and args.cpu_budget > 0:
                 out["cpu_baseline"] = cpu_baseline(args.blocks, m["C"], args.cpu_budget, args.rollout)

@@ -2,7 +2,7 @@
 #include "nn_kernels.hpp"
 #include "nn_tower32.hpp"
 #ifdef SC_EXP
-#include "nn_tower16.hpp"
+#include "../../tools/experiments/nn_tower16.hpp"   // not part of the product tree
 #endif
 #ifndef SC_T32_RS
 #define SC_T32_RS 12   // narrow trunk: 12-slot weight ring, all 9 taps of a conv unrolled (no tap-group loop: measured

@@ -5,7 +5,7 @@
 namespace scnn {
 struct NetLayout {
     int n_blocks, C;
-    int tower32;  // 1: trunk/head convs packed for k_tower32 (32x32x16 A fragments), 0: the experiment-only pixel-major kernel (nn_tower16.hpp, 16x16x32 B fragments)
+    int tower32;  // 1: trunk/head convs packed for k_tower32 (32x32x16 A fragments), 0: the experiment-only pixel-major kernel (tools/experiments/nn_tower16.hpp, 16x16x32 B fragments)
     // element offsets into the bf16 blob (MFMA B-fragment packed GEMM operands)
     size_t o_stem, o_blocks, blk_stride_b, o_vconv, o_pconv1, o_pconv2, o_fc1;
     // element offsets into the fp32 blob (per-channel parameters, logical channel order)

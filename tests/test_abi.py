@@ -22,15 +22,41 @@ def scamd():
     return m
 
 
-def test_exports_every_declared_symbol(scamd):
+def test_exports_exactly_the_declared_symbols(scamd):
+    """header <-> library <-> binding: every declared entry point is exported, and nothing is exported that the header
+    does not declare (no hidden developer entry points)"""
+    import subprocess
     hdr = open(os.path.join(ROOT, "include", "sc_engine.h")).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
     declared = set(re.findall(r"\b(sc_[a-z_0-9]+)\s*\(", hdr))
-    assert len(declared) >= 25
+    assert len(declared) >= 30
     L = C.CDLL(scamd.lib_path())
     for name in declared:
         assert hasattr(L, name), name
     assert declared == set(scamd.binding.ABI), declared ^ set(scamd.binding.ABI)
+    nm = subprocess.run(["nm", "-D", "--defined-only", scamd.lib_path()], capture_output=True, text=True, check=True).stdout
+    exported = {ln.split()[-1] for ln in nm.splitlines() if len(ln.split()) == 3 and ln.split()[1] in "TW" and ln.split()[-1].startswith("sc_")}
+    assert exported == declared, exported ^ declared
+
+
+def test_runtime_flags_report_the_kernarg_switch(scamd):
+    """the load hook's effect on the process environment is queryable, and can be switched off (sc_engine.h)"""
+    import subprocess
+    import sys
+    # (os.environ is a snapshot taken at interpreter start: ask the C library for the live value)
+    code = ("import ctypes; L = ctypes.CDLL(%r); g = ctypes.CDLL(None).getenv; g.restype = ctypes.c_char_p; "
+            "v = g(b'HIP_FORCE_DEV_KERNARG'); print(L.sc_runtime_flags(), v.decode() if v else None)" % scamd.lib_path())
+
+    def run(env_extra, drop=()):
+        env = {k: v for k, v in os.environ.items() if k not in ("HIP_FORCE_DEV_KERNARG", "SC_ENGINE_KEEP_ENV") + tuple(drop)}
+        env.update(env_extra)
+        # (the library is loaded directly: the ctypes binding sets the variable itself first -- it owns its process)
+        return subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, check=True).stdout.split()
+
+    assert run({}) == ["3", "1"]                                  # set by the load hook: bits 0 + 1
+    assert run({"HIP_FORCE_DEV_KERNARG": "1"}) == ["1", "1"]      # set by the host: effective for sure
+    assert run({"HIP_FORCE_DEV_KERNARG": "0"}) == ["0", "0"]      # an explicit setting of the host wins
+    assert run({"SC_ENGINE_KEEP_ENV": "1"}) == ["4", "None"]      # hook disabled: the environment is left alone
 
 
 def test_product_does_not_reference_the_oracle():

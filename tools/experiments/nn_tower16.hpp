@@ -3,7 +3,7 @@
 // with SC_TOWER_V=1): it was the production kernel of the wide trunk until the channel-major tower (nn_tower32.hpp)
 // overtook it at both widths and is kept as the A/B baseline.  Same contract as k_tower32.
 #pragma once
-#include "nn_kernels.hpp"
+#include "../../smart-chess-rust_amd/csrc/nn_kernels.hpp"
 
 namespace scnn {
 
