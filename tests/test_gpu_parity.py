@@ -95,7 +95,9 @@ def test_network_matches_bf16_emulating_oracle(scamd, orc, C, nb):
     lat = eng.debug(g["boards"][:1], g["meta"][:1], 1000)[0]
     for k in range(4):
         ol, ov, olat = net.forward(g["boards"][k], g["meta"][k], latent=True)
-        assert np.abs(logp[k] - ol).max() < (2e-2 if nb < 10 else 5e-2) and abs(val[k] - ov) < 5e-3
+        print(f"C={C} nb={nb} k={k}: max|dlogp|={np.abs(logp[k] - ol).max():.4f} |dvalue|={abs(val[k] - ov):.5f}")
+        # bounds = 2x the maxima observed on the MI355X: |dlogp| 0.0095 below 10 blocks, 0.0207 at 19; |dvalue| 0.0012
+        assert np.abs(logp[k] - ol).max() < (2e-2 if nb < 10 else 4.2e-2) and abs(val[k] - ov) < 2.5e-3
         if k == 0:
             assert np.abs(lat - olat).max() < 5e-2 * max(1.0, np.abs(olat).max())
     eng.close()

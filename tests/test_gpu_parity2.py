@@ -86,12 +86,14 @@ def test_search_with_exact_ties_lockstep(scamd, orc, evaluator, oeval, line):
         srch.sim(evaluator=oeval, cpuct=2.5, with_noise=False)
         path = list(sp.slot(0)["path"])
         assert path == list(srch.last_path()), s
-        if evaluator == "synth_uniform" and 1 <= s <= n_root:
-            assert path[1] == n_root + 1 - s, s           # children are visited last to first while they tie
+        if evaluator == "synth_uniform" and 1 <= s <= (n_root if not line else 60):
+            # children are visited last to first while they all tie (in the wide position a mating move is among the
+            # 82: its +1 reward ends the pure tie pattern once it has been visited)
+            assert path[1] == n_root + 1 - s, s
         if s % 5 == 0 or s > R - 4:
             assert _same_tree(sp.tree(0), srch.dump()), s
     t = sp.tree(0)
-    if evaluator == "synth_uniform":
+    if evaluator == "synth_uniform" and not line:
         u = t["uct"][1:1 + n_root]
         assert (u == u.max()).sum() > 1                    # the last selection at the root still saw an exact tie
     assert sp.stats()["error_flags"] == 0
@@ -135,7 +137,7 @@ def test_network_matches_reference_goldens_deep(scamd, nb):
     logp, val = eng.forward(g["boards"], g["meta"])
     d = float(np.abs(logp - g["logp"]).max())
     print(f"nb={nb} max|dlogp|={d:.4f} max|dvalue|={float(np.abs(val - g['value']).max()):.5f}")
-    np.testing.assert_allclose(logp, g["logp"], rtol=RTOL, atol=3 * ATOL)   # deeper stack: observed <= 0.02 at 20 blocks
+    np.testing.assert_allclose(logp, g["logp"], rtol=RTOL, atol=3 * ATOL)   # deeper stack: observed max |dlogp| 0.022 (19 blocks), 0.020 (20)
     np.testing.assert_allclose(val, g["value"], rtol=RTOL, atol=ATOL)
     # priors of the legal moves (what the search consumes): total variation distance (validate_inference.py:22-23)
     p_ref, p_hip = np.exp(g["logp"].astype(np.float64)), np.exp(logp.astype(np.float64))
@@ -161,7 +163,7 @@ def test_network_10x128_on_64_positions(scamd, orc):
         dv.append(abs(val[k] - ov))
         dp.append(0.5 * np.abs(np.exp(logp[k].astype(np.float64)) - np.exp(ol.astype(np.float64))).sum())
     print(f"10x128: max|dlogp|={max(dl):.4f} max|dvalue|={max(dv):.5f} max TVD={max(dp):.5f}")
-    assert max(dl) < 4e-2 and max(dv) < 4e-3 and max(dp) < 4e-3
+    assert max(dl) < 4e-2 and max(dv) < 3e-3 and max(dp) < 3.5e-3   # observed 0.0214 / 0.00132 / 0.00171
     eng.close()
 
 
@@ -229,7 +231,8 @@ def test_rollout_factor_games_exact(scamd, orc):
             ref = orc.selfplay_game(rollout_num=300, rollout_factor=factor, seed=17, game_id=tr["game_id"], outcome_gate=100, **cfg)
             assert tr["steps"] == ref["steps"] and tr["outcome"] == ref["outcome"], (factor, gi)
         budgets = {sum(c[1] for c in s[2]) + 1 for s in sp.trace(0)["steps"]}
-        assert (budgets == {300}) if factor == 20.0 else (len(budgets) > 1 and max(budgets) < 300)
+        # 20 x n_legal hits the cap of 300 unless the side to move has < 15 legal moves (check evasions)
+        assert (max(budgets) == 300) if factor == 20.0 else (len(budgets) > 1 and max(budgets) < 300)
         sp.close()
     with pytest.raises(scamd.EngineError):
         scamd.SelfPlay(None, n_slots=1, rollout_num=100, rollout_factor=2.0, evaluator="synth")
