@@ -54,17 +54,28 @@ int sc_runtime_flags(void);
 const char* sc_last_warning(void);
 
 /* ------------------------------------------------------------------ network (L-predict) */
+enum { SC_PREC_BF16 = 0, SC_PREC_FP8 = 1 };
 typedef struct {
     int32_t n_res_blocks;  /* py/module.py:110 (reference default 19) */
     int32_t channels;      /* trunk width: 256 in the reference (py/module.py:120-133); 128 = BASELINE cfg2 variant */
     uint64_t seed;         /* used when weights_path == NULL: build-owned deterministic init (tools/scw.py) */
+    int32_t precision;     /* SC_PREC_BF16: the reference's exported precision (py/export.py:47-65, bf16 autocast).
+                              SC_PREC_FP8 (BASELINE configs[4]): the convs (stem, blocks, head convs) run on the CDNA4 fp8
+                              matrix cores -- OCP e4m3 operands, per-output-channel power-of-two weight scales, fp32
+                              accumulate; LayerNorm / residual stream / softmax fp32 and the SE + value FC layers bf16 as
+                              before.  Stated tolerance vs the fp32 reference vectors: prior total
+                              variation < 0.05, |value| error < 0.05. */
+    int32_t reserved;
 } sc_net_config;
 
 /* Replaces backend construction in src/main.rs:83-128 (ChessTS / ChessEP / ChessOnnx).
- * weights_path: SCW1 blob written by tools/scw.py from a reference state_dict, or NULL. */
+ * weights_path: NULL, or a blob written by tools/scw.py / tools/ckpt_to_scw.py from a reference state_dict: SCW1 (fp32
+ * tensors; quantised at load as cfg->precision asks) or SCW2 (the fp8 export: e4m3 conv weights + their channel scales;
+ * the blob's precision wins). */
 int sc_engine_create(const sc_net_config* cfg, const char* weights_path, int device_id, sc_engine** out);
 void sc_engine_destroy(sc_engine*);
 int sc_engine_max_batch(const sc_engine*);
+int sc_engine_precision(const sc_engine*);   /* SC_PREC_* the engine runs in */
 
 /* ChessModule.forward on a batch (src/backends/torch.rs:115-125, py/module.py:135-154):
  * host buffers in, logp [n][4672] fp32 (log-softmax, channel-major flatten) and value [n] out

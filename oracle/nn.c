@@ -11,9 +11,12 @@
  * `channels` is 256 in the reference (module.py:120-133); 128 is the build-defined variant of
  * BASELINE.json configs[1] (trunk C=128, heads 256 wide).
  *
- * emulate_bf16: round GEMM operands (weights + conv/linear inputs) to bfloat16 the way the HIP
+ * emulate_bf16 = 1: round GEMM operands (weights + conv/linear inputs) to bfloat16 the way the HIP
  * engine does, keeping fp32 accumulate / LayerNorm / residual.  Used to separate quantisation
  * error from kernel bugs; the parity claim vs the reference is made against the fp32 mode.
+ * emulate_bf16 = 2: the engine's fp8 mode (BASELINE configs[4]; no reference counterpart): the
+ * convs (stem, residual blocks, the three head convs) take OCP e4m3 operands -- weights with one power-of-two scale per
+ * output channel, inputs clamped to +-448 and rounded to nearest even -- everything else as in mode 1.
  */
 #include "sc_oracle_nn.h"
 #include <math.h>
@@ -27,6 +30,33 @@ static float bf16_round(float x) {
     u = (u + 0x7fffu + ((u >> 16) & 1u)) & 0xffff0000u;
     memcpy(&x, &u, 4);
     return x;
+}
+
+/* OCP e4m3: 4 exponent bits (bias 7), 3 mantissa bits, subnormals of 2^-9, maximum 448, no infinity.  The same rules
+ * as smart-chess-rust_amd/csrc/weights.hpp and tools/scw.py. */
+float orc_e4m3_round(float x) {
+    if (x != x) return x;
+    float a = fabsf(x);
+    if (a > 448.f) a = 448.f;
+    int ex;
+    (void)frexpf(a, &ex);
+    float q = a >= 0.015625f ? ldexpf(1.f, ex - 4) : 0.001953125f;
+    float r = nearbyintf(a / q) * q;
+    return x < 0 ? -r : r;
+}
+int orc_fp8_channel_exp(float maxabs) {
+    if (!(maxabs > 0.f)) return 0;
+    int ex;
+    float f = frexpf(maxabs / 448.f, &ex);
+    int e = f == 0.5f ? ex - 1 : ex;
+    return e < -100 ? -100 : e > 100 ? 100 : e;
+}
+static int is_fp8_conv(int n_blocks, int t) {
+    if (t == 0) return 1;
+    t -= 4;
+    if (t >= 0 && t < 12 * n_blocks) return t % 12 == 0 || t % 12 == 4;
+    t -= 12 * n_blocks;
+    return t == 0 || t == 8 || t == 12;
 }
 
 /* ---- deterministic weights shared with the engine and tools/scw.py ---- */
@@ -119,12 +149,20 @@ static void derive(struct orc_net* n, int t) {
     const float* s = n->w[t];
     if (nd == 4) {
         int O = shape[0], I = shape[1], K = shape[2] * shape[3];
-        for (int o = 0; o < O; o++)
+        int fp8 = n->emulate_bf16 == 2 && is_fp8_conv(n->n_blocks, t);
+        for (int o = 0; o < O; o++) {
+            int e = 0;
+            if (fp8) {
+                float m = 0;
+                for (int64_t q = 0; q < (int64_t)I * K; q++) m = fmaxf(m, fabsf(s[(int64_t)o * I * K + q]));
+                e = orc_fp8_channel_exp(m);
+            }
             for (int i = 0; i < I; i++)
                 for (int k = 0; k < K; k++) {
                     float v = s[((int64_t)o * I + i) * K + k];
-                    d[((int64_t)k * I + i) * O + o] = n->emulate_bf16 ? bf16_round(v) : v;
+                    d[((int64_t)k * I + i) * O + o] = fp8 ? ldexpf(orc_e4m3_round(ldexpf(v, -e)), e) : n->emulate_bf16 ? bf16_round(v) : v;
                 }
+        }
     } else {
         int O = shape[0], I = shape[1];
         for (int o = 0; o < O; o++)
@@ -181,6 +219,15 @@ int orc_net_get_tensor(const orc_net* n, int t, float* out, int64_t numel) {
 }
 
 /* ---- layers; activations are [64 pixels][C] fp32 (pixel = rank*8+file) ---- */
+/* input of a conv that runs in e4m3 in mode 2 */
+static void round_conv_in(const struct orc_net* n, const float* in, float* out, int64_t cnt) {
+    if (n->emulate_bf16 == 2)
+        for (int64_t i = 0; i < cnt; i++) out[i] = orc_e4m3_round(in[i]);
+    else if (n->emulate_bf16)
+        for (int64_t i = 0; i < cnt; i++) out[i] = bf16_round(in[i]);
+    else if (in != out)
+        memcpy(out, in, sizeof(float) * (size_t)cnt);
+}
 static void maybe_round(const struct orc_net* n, const float* in, float* out, int64_t cnt) {
     if (n->emulate_bf16)
         for (int64_t i = 0; i < cnt; i++) out[i] = bf16_round(in[i]);
@@ -244,10 +291,10 @@ void orc_net_forward(const orc_net* n, const int8_t* boards, const int32_t* meta
     layernorm(x, C, n->w[2], n->w[3], 1);
     for (int b = 0; b < n->n_blocks; b++) {
         int t = 4 + 12 * b;
-        maybe_round(n, x, a, 64 * C);
+        round_conv_in(n, x, a, 64 * C);
         conv(a, C, n->wt[t + 0], n->w[t + 1], C, 3, t1);
         layernorm(t1, C, n->w[t + 2], n->w[t + 3], 1);
-        maybe_round(n, t1, a, 64 * C);
+        round_conv_in(n, t1, a, 64 * C);
         conv(a, C, n->wt[t + 4], n->w[t + 5], C, 3, t2);
         layernorm(t2, C, n->w[t + 6], n->w[t + 7], 0);
         /* squeeze-excitation */
@@ -277,11 +324,11 @@ void orc_net_forward(const orc_net* n, const int8_t* boards, const int32_t* meta
     }
     if (dbg_latent) memcpy(dbg_latent, x, sizeof(float) * 64 * (size_t)C);
     int vt = 4 + 12 * n->n_blocks, pt = vt + 8;
-    maybe_round(n, x, a, 64 * C);
+    round_conv_in(n, x, a, 64 * C);
     /* policy head (module.py:70-80) */
     conv(a, C, n->wt[pt + 0], n->w[pt + 1], H, 1, t1);
     layernorm(t1, H, n->w[pt + 2], n->w[pt + 3], 0);
-    maybe_round(n, t1, t1, 64 * H);
+    round_conv_in(n, t1, t1, 64 * H);
     conv(t1, H, n->wt[pt + 4], n->w[pt + 5], 73, 1, t2);
     layernorm(t2, 73, n->w[pt + 6], n->w[pt + 7], 0);
     {

@@ -99,6 +99,8 @@ def lib():
         "orc_net_tensor_shape": (C.c_int64, [i32, i32, i32, C.POINTER(i32), C.POINTER(i32)]),
         "orc_prng_weight": (C.c_float, [u64, i32, u64, C.c_double, C.c_double]),
         "orc_net_create": (vp, [i32, i32, u64, i32]),
+        "orc_e4m3_round": (C.c_float, [C.c_float]),
+        "orc_fp8_channel_exp": (i32, [C.c_float]),
         "orc_net_free": (None, [vp]),
         "orc_net_set_tensor": (i32, [vp, i32, vp, C.c_int64]),
         "orc_net_get_tensor": (i32, [vp, i32, vp, C.c_int64]),
@@ -251,10 +253,11 @@ def move_index(m, turn):
 
 
 class Net:
-    def __init__(self, n_blocks, channels=256, seed=0, emulate_bf16=False):
+    def __init__(self, n_blocks, channels=256, seed=0, emulate_bf16=False, emulate_fp8=False):
+        """emulate_bf16 / emulate_fp8: round the GEMM operands the way the engine's bf16 / fp8 mode does (nn.c header)"""
         self.L = lib()
         self.n_blocks, self.channels = n_blocks, channels
-        self.h = self.L.orc_net_create(n_blocks, channels, seed, int(emulate_bf16))
+        self.h = self.L.orc_net_create(n_blocks, channels, seed, 2 if emulate_fp8 else int(emulate_bf16))
 
     def __del__(self):
         try:

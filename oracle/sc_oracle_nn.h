@@ -15,7 +15,11 @@ int64_t orc_net_tensor_shape(int n_blocks, int channels, int t, int shape[4], in
 /* build-owned deterministic weight generator (same function in tools/scw.py and the engine) */
 float orc_prng_weight(uint64_t seed, int tensor, uint64_t idx, double scale, double shift);
 
-orc_net* orc_net_create(int n_blocks, int channels, uint64_t seed, int emulate_bf16);
+/* emulate: 0 fp32 (the parity reference), 1 the engine's bf16 operand rounding, 2 its fp8 (e4m3) mode (nn.c header) */
+orc_net* orc_net_create(int n_blocks, int channels, uint64_t seed, int emulate);
+/* OCP e4m3 rounding (nearest even, subnormals, clamp to +-448) and the per-output-channel power-of-two weight scale rule */
+float orc_e4m3_round(float x);
+int orc_fp8_channel_exp(float maxabs);
 void orc_net_free(orc_net*);
 int orc_net_set_tensor(orc_net*, int t, const float* data, int64_t numel);
 int orc_net_get_tensor(const orc_net*, int t, float* out, int64_t numel);

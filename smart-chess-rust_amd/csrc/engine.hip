@@ -187,6 +187,8 @@ int sc_engine_create(const sc_net_config* cfg, const char* weights_path, int dev
         if (cfg->n_res_blocks < 0 || cfg->n_res_blocks > 80) return fail("n_res_blocks out of range");
         hw = scw::init_prng(cfg->n_res_blocks, cfg->channels, cfg->seed);
     }
+    if (cfg->precision != SC_PREC_BF16 && cfg->precision != SC_PREC_FP8) return fail("unknown precision");
+    if (cfg->precision == SC_PREC_FP8) hw.fp8 = true;   // (an SCW2 fp8 blob sets it by itself)
     // Both trunk widths run the channel-major 32x32x16 tower.  Experiment builds also carry the
     // pixel-major 16x16x32 kernel; SC_TOWER_V=1 selects it there (developer switch, ignored by the production build).
     const int tv = getenv("SC_TOWER_V") ? atoi(getenv("SC_TOWER_V")) : 0;
@@ -238,6 +240,7 @@ void sc_engine_destroy(sc_engine* e) {
 }
 
 int sc_engine_max_batch(const sc_engine*) { return 65536; }
+int sc_engine_precision(const sc_engine* e) { return e && e->net.fp8 ? SC_PREC_FP8 : SC_PREC_BF16; }
 int sc_engine_synchronize(sc_engine* e) {
     if (!e) return fail("null engine");
     HIPOK(hipSetDevice(e->device));

@@ -14,6 +14,22 @@
 #define SC_T32W_TPI 1   // within 0.5 % of each other)
 #endif
 
+// fp8 (e4m3) towers: k-steps of 64 (half as many, twice as long: the same bytes in flight need half the ring slots)
+#ifndef SC_T8_RS
+#define SC_T8_RS 6
+#define SC_T8_TPI 3
+#define SC_T8_AB 3
+#endif
+#ifndef SC_T8W_RS
+#define SC_T8W_RS 6
+#define SC_T8W_TPI 3
+#define SC_T8W_AB 3
+#endif
+#define K_T32N scnn::k_tower32<scnn::PrecBF16, 128, SC_T32_RS, SC_T32_TPI>
+#define K_T32W scnn::k_tower32<scnn::PrecBF16, 256, SC_T32W_RS, SC_T32W_TPI>
+#define K_T8N scnn::k_tower32<scnn::PrecFP8, 128, SC_T8_RS, SC_T8_TPI, SC_T8_AB>
+#define K_T8W scnn::k_tower32<scnn::PrecFP8, 256, SC_T8W_RS, SC_T8W_TPI, SC_T8W_AB>
+
 #include <stdlib.h>
 
 #include <algorithm>
@@ -37,12 +53,13 @@ size_t tower_lds_bytes(int C) {
 // (-DSC_EXP, tools/build_exp.sh) also carry the pixel-major 16x16x32 kernel (nn_kernels.hpp) of each width for A/B runs
 // (SC_TOWER_V=1 at engine creation picks its weight packing, and with it the kernel).
 const char* nn_init() {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scnn::k_tower32<128, SC_T32_RS, SC_T32_TPI>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, scnn::tower32_lds_bytes(128));
-    if (e != hipSuccess) return hipGetErrorString(e);
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scnn::k_tower32<256, SC_T32W_RS, SC_T32W_TPI>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, scnn::tower32_lds_bytes(256));
-    if (e != hipSuccess) return hipGetErrorString(e);
+    hipError_t e = hipSuccess;
+    const void* kn[4] = {reinterpret_cast<const void*>(&K_T32N), reinterpret_cast<const void*>(&K_T32W),
+                         reinterpret_cast<const void*>(&K_T8N), reinterpret_cast<const void*>(&K_T8W)};
+    for (int i = 0; i < 4; i++) {
+        e = hipFuncSetAttribute(kn[i], hipFuncAttributeMaxDynamicSharedMemorySize, scnn::tower32_lds_bytes(i & 1 ? 256 : 128));
+        if (e != hipSuccess) return hipGetErrorString(e);
+    }
 #ifdef SC_EXP
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scnn::k_tower<256, 4, 1>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)tower16_lds_bytes(256));
@@ -70,10 +87,14 @@ bool tower_variant_available(int C, bool tower32) {
 void tower(const scnn::TowerArgs& a, hipStream_t s) {
     if (a.n_pos <= 0) return;
     const scnn::TowerArgs& b = a;
-    if (a.net.tower32 && a.net.C == 128)
-        hipLaunchKernelGGL((scnn::k_tower32<128, SC_T32_RS, SC_T32_TPI>), dim3(a.n_pos), dim3(256), scnn::tower32_lds_bytes(128), s, b);
+    if (a.net.tower32 && a.net.fp8 && a.net.C == 128)
+        hipLaunchKernelGGL(K_T8N, dim3(a.n_pos), dim3(256), scnn::tower32_lds_bytes(128), s, b);
+    else if (a.net.tower32 && a.net.fp8)
+        hipLaunchKernelGGL(K_T8W, dim3(a.n_pos), dim3(256), scnn::tower32_lds_bytes(256), s, b);
+    else if (a.net.tower32 && a.net.C == 128)
+        hipLaunchKernelGGL(K_T32N, dim3(a.n_pos), dim3(256), scnn::tower32_lds_bytes(128), s, b);
     else if (a.net.tower32)
-        hipLaunchKernelGGL((scnn::k_tower32<256, SC_T32W_RS, SC_T32W_TPI>), dim3(a.n_pos), dim3(256), scnn::tower32_lds_bytes(256), s, b);
+        hipLaunchKernelGGL(K_T32W, dim3(a.n_pos), dim3(256), scnn::tower32_lds_bytes(256), s, b);
 #ifdef SC_EXP
     else if (a.net.C == 256)
         hipLaunchKernelGGL((scnn::k_tower<256, 4, 1>), dim3(a.n_pos), dim3(256), tower16_lds_bytes(256), s, b);

@@ -26,6 +26,68 @@
 namespace scnn {
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+
+// --------------------------------------------------------------------------------------------
+// Precision policies of the conv GEMMs (stem, residual blocks, the three head convs).  Everything else -- fp32
+// accumulators, LayerNorm, residual stream, the bf16 squeeze-excitation and value FC layers, the fp32 softmax -- is shared.
+//   PrecBF16  operands bf16, v_mfma_f32_32x32x16_bf16 (K = 16 per instruction, 32 cycles)
+//   PrecFP8   operands OCP e4m3 (BASELINE configs[4]), v_mfma_scale_f32_32x32x64_f8f6f4 (K = 64 per instruction, 64
+//             cycles: twice the MACs per cycle).  The block scales of the instruction carry the per-output-channel
+//             power-of-two weight scales (E8M0, one byte per lane = per row of the A tile) for free; the image operand's
+//             scale is 2^0.  Lane maps pinned with exact data by tools/experiments/mfma_fp8_layout.hip: lane l holds
+//             row/column l & 31, k = 32 (l >> 5) .. + 31, one scale byte per lane applies to its row.
+//             Activations are clamped to +-448 before v_cvt_pk_fp8_f32 (which overflows to NaN, not to the maximum).
+struct PrecBF16 {
+    static constexpr bool FP8 = false;
+    static constexpr int EB = 2;     // bytes per image / weight element
+    static constexpr int KS = 16;    // k per MFMA
+    static constexpr int FB = 16;    // fragment bytes per lane (one ds_read_b128 / one 16-byte weight load)
+    typedef bf16x8 frag;
+};
+struct PrecFP8 {
+    static constexpr bool FP8 = true;
+    static constexpr int EB = 1;
+    static constexpr int KS = 64;
+    static constexpr int FB = 32;    // two 16-byte halves: image bytes [32h, 32h + 32) of the k-step, weights [half][lane][16]
+    typedef i32x8 frag;
+};
+// haloed image: pixel stride in bytes -- an odd multiple of 16 B at both precisions (272 / 528 B bf16, 144 / 272 B fp8)
+template <class P>
+constexpr int pix_stride(int channels) { return channels * P::EB + 16; }
+
+template <class P>
+__device__ __forceinline__ typename P::frag lds_frag_p(int byte_off) {
+    if constexpr (P::FP8) {
+        typedef __attribute__((ext_vector_type(4))) int i32x4;
+        const i32x4 a = *reinterpret_cast<const i32x4*>(g_smem + byte_off), b = *reinterpret_cast<const i32x4*>(g_smem + byte_off + 16);
+        return i32x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    } else {
+        return lds_frag(byte_off);
+    }
+}
+// one weight fragment of channel tile ct (voff = lane * 16, soff = scalar cursor): 64 * FB bytes per tile
+template <class P>
+__device__ __forceinline__ typename P::frag wload_p(__amdgpu_buffer_rsrc_t rsrc, int voff, int ct, int soff) {
+    if constexpr (P::FP8) {
+        const bf16x8 a = wload(rsrc, voff + ct * 2048, soff), b = wload(rsrc, voff + ct * 2048 + 1024, soff);
+        typedef __attribute__((ext_vector_type(4))) int i32x4;
+        const i32x4 x = __builtin_bit_cast(i32x4, a), y = __builtin_bit_cast(i32x4, b);
+        return i32x8{x[0], x[1], x[2], x[3], y[0], y[1], y[2], y[3]};
+    } else {
+        return wload(rsrc, voff + ct * 1024, soff);
+    }
+}
+template <class P>
+__device__ __forceinline__ f32x16 mma_p(const typename P::frag& a, const typename P::frag& b, const f32x16& c, int scale_a) {
+    if constexpr (P::FP8) return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 0, 0, 0, scale_a, 0, 127);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+// four adjacent channels of one pixel -> the image (8 bytes bf16 / 4 bytes e4m3), optionally through ReLU
+__device__ __forceinline__ uint32_t pk_fp8x4(float a, float b, float c, float d) {
+    int w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+    return (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
+}
 
 // experiment builds (-DSC_EXP, tools/build_exp.sh): per-wave cycle stamps of the block phases, dumped with dbg_stage 2000
 #ifdef SC_EXP
@@ -74,6 +136,19 @@ __device__ __forceinline__ uint32_t pk_bf16_relu(f32x2 y) {
     return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(s, s16x2{0, 0}));
 }
 
+template <class P, bool RELU>
+__device__ __forceinline__ void store4(int byte_off_row, int chan, f32x2 lo, f32x2 hi) {
+    if constexpr (P::FP8) {
+        const float l = RELU ? 0.f : -448.f;   // med3 = clamp (and ReLU): e4m3 has no infinity, the convert does not saturate
+        *reinterpret_cast<uint32_t*>(g_smem + byte_off_row + chan) =
+            pk_fp8x4(__builtin_amdgcn_fmed3f(lo.x, l, 448.f), __builtin_amdgcn_fmed3f(lo.y, l, 448.f),
+                     __builtin_amdgcn_fmed3f(hi.x, l, 448.f), __builtin_amdgcn_fmed3f(hi.y, l, 448.f));
+    } else {
+        *reinterpret_cast<uint2*>(g_smem + byte_off_row + chan * 2) =
+            RELU ? make_uint2(pk_bf16_relu(lo), pk_bf16_relu(hi)) : make_uint2(pk_bf16(lo), pk_bf16(hi));
+    }
+}
+
 // first channel of register quad g (registers 4g..4g+3) of channel tile ct
 template <int CT>
 __device__ __forceinline__ int chan32(int wave, int ct, int g, int h) { return wave * (32 * CT) + ct * 32 + 8 * g + 4 * h; }
@@ -119,21 +194,25 @@ __device__ __forceinline__ void acc_init(f32x16 (&acc)[CT][2], const ChP<CT>& B)
 #ifndef SC_T32_AB
 #define SC_T32_AB 4
 #endif
-template <int CIN, int TAPS, int CT, int TILES, int CP, int RS, int TPI, bool PRE, int AB = SC_T32_AB>
+//   PSB: pixel stride of the image in bytes; sa: E8M0 weight scales of this wave's channel tiles (fp8 only)
+template <class P, int CIN, int TAPS, int CT, int TILES, int PSB, int RS, int TPI, bool PRE, int AB = SC_T32_AB>
 __device__ __forceinline__ void conv_mma32(int xoff, const bf16_t* __restrict__ Wp, int wave_u, int lane, const int (&px)[2],
-                                           f32x16 (&acc)[CT][2], bf16x8 (&bq)[RS][CT], int next_first) {
-    constexpr int KPT = CIN / 16;          // k-steps per tap
+                                           f32x16 (&acc)[CT][2], typename P::frag (&bq)[RS][CT], int next_first, const int (&sa)[CT]) {
+    typedef typename P::frag frag;
+    constexpr int KPT = CIN / P::KS;       // k-steps per tap
     constexpr int SPG = KPT * TPI;         // k-steps per loop iteration (tap group)
     constexpr int NG = TAPS / TPI;
-    constexpr int SBB = TILES * 1024;      // bytes per k-step of packed weights
+    constexpr int TB = 64 * P::FB;         // bytes of one tile's fragment (a wave-load, or two at fp8)
+    constexpr int SBB = TILES * TB;        // bytes per k-step of packed weights
+    constexpr int KSB = P::KS * P::EB;     // image bytes per k-step
     constexpr int PD = RS - 1, AD = AB - 1;
     static_assert(TAPS % TPI == 0 && SPG % RS == 0 && PD < SPG, "bad ring / tap-group geometry");
     static_assert(SPG % AB == 0 && AD <= SPG, "bad image buffer geometry");
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<bf16_t*>(Wp) + (size_t)wave_u * CT * 512, 0, 0x7fffffff, 0x00020000);
+        const_cast<bf16_t*>(Wp) + (size_t)wave_u * CT * (TB / 2), 0, 0x7fffffff, 0x00020000);
     const int voff = lane * 16;
-    auto toffb = [](int t) { return (TAPS == 9) ? ((((t * 11) >> 5) - 1) * 10 + (t - 3 * ((t * 11) >> 5)) - 1) * CP * 2 : 0; };
-    bf16x8 xq[AB][2];
+    auto toffb = [](int t) { return (TAPS == 9) ? ((((t * 11) >> 5) - 1) * 10 + (t - 3 * ((t * 11) >> 5)) - 1) * PSB : 0; };
+    frag xq[AB][2];
     int wcur = 0;
     int pc[TPI][2];
 #pragma unroll
@@ -144,12 +223,12 @@ __device__ __forceinline__ void conv_mma32(int xoff, const bf16_t* __restrict__ 
 #pragma unroll
         for (int st = 0; st < PD; st++)
 #pragma unroll
-            for (int ct = 0; ct < CT; ct++) bq[st][ct] = wload(rsrc, voff + ct * 1024, st * SBB);
+            for (int ct = 0; ct < CT; ct++) bq[st][ct] = wload_p<P>(rsrc, voff, ct, st * SBB);
     }
 #pragma unroll
     for (int v = 0; v < AD; v++)
 #pragma unroll
-        for (int pt = 0; pt < 2; pt++) xq[v][pt] = lds_frag(pc[v / KPT][pt] + (v % KPT) * 32);
+        for (int pt = 0; pt < 2; pt++) xq[v][pt] = lds_frag_p<P>(pc[v / KPT][pt] + (v % KPT) * KSB);
 #pragma unroll 1
     for (int j = 0; j < NG; j++) {
         const int tn = (j + 1 == NG) ? 0 : j + 1;
@@ -164,24 +243,29 @@ __device__ __forceinline__ void conv_mma32(int xoff, const bf16_t* __restrict__ 
             const int slot = u % RS;
 #pragma unroll
             for (int ct = 0; ct < CT; ct++)
-                bq[(slot + PD) % RS][ct] = (u + PD < SPG) ? wload(rsrc, voff + ct * 1024, wcur + (u + PD) * SBB)
-                                                          : wload(rsrc, voff + ct * 1024, wnext + (u + PD - SPG) * SBB);
+                bq[(slot + PD) % RS][ct] = (u + PD < SPG) ? wload_p<P>(rsrc, voff, ct, wcur + (u + PD) * SBB)
+                                                          : wload_p<P>(rsrc, voff, ct, wnext + (u + PD - SPG) * SBB);
 #pragma unroll
             for (int pt = 0; pt < 2; pt++) {
                 const int v = u + AD;
-                xq[v % AB][pt] = (v < SPG) ? lds_frag(pc[v / KPT][pt] + (v % KPT) * 32)
-                                           : lds_frag(pn[(v - SPG) / KPT][pt] + ((v - SPG) % KPT) * 32);
+                xq[v % AB][pt] = (v < SPG) ? lds_frag_p<P>(pc[v / KPT][pt] + (v % KPT) * KSB)
+                                           : lds_frag_p<P>(pn[(v - SPG) / KPT][pt] + ((v - SPG) % KPT) * KSB);
             }
 #pragma unroll
             for (int ct = 0; ct < CT; ct++)
 #pragma unroll
                 for (int pt = 0; pt < 2; pt++)
-                    acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq[slot][ct], xq[u % AB][pt], acc[ct][pt], 0, 0, 0);
-            // one memory instruction behind each MFMA; the fence keeps every prefetch in the step it was written in
+                    acc[ct][pt] = mma_p<P>(bq[slot][ct], xq[u % AB][pt], acc[ct][pt], sa[ct]);
+            // one memory instruction behind each MFMA (two at fp8: its fragments are two 16-byte halves); the fence
+            // keeps every prefetch in the step it was written in
 #pragma unroll
             for (int m = 0; m < 2 * CT; m++) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                if (CT == 1) {
+                if (P::FP8) {
+                    // per k-step: 2 CT weight loads and 4 image reads ride under 2 CT MFMAs of 64 cycles
+                    __builtin_amdgcn_sched_group_barrier(0x100, CT == 1 ? 2 : 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                } else if (CT == 1) {
                     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                     if (m == 0) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
                 } else {
@@ -274,7 +358,7 @@ __device__ __forceinline__ void ln_apply(f32x16 (&acc)[CT][2], const LnStat& L, 
             }
 }
 // LayerNorm scale/shift + ReLU straight into the bf16 image (the fp32 values are not needed again)
-template <int CT>
+template <class P, int CT>
 __device__ __forceinline__ void ln_apply_relu_store(const f32x16 (&acc)[CT][2], const LnStat& L, const ChP<CT>& G, const ChP<CT>& E,
                                                     const int (&pixbase)[2], int wave, int h) {
 #pragma unroll
@@ -283,13 +367,13 @@ __device__ __forceinline__ void ln_apply_relu_store(const f32x16 (&acc)[CT][2], 
         for (int pt = 0; pt < 2; pt++)
 #pragma unroll
             for (int g = 0; g < 4; g++) {
-                uint32_t w[2];
+                f32x2 y[2];
 #pragma unroll
                 for (int hf = 0; hf < 2; hf++) {
                     const f32x2 t = pair(acc[ct][pt], 4 * g + 2 * hf) * splat(L.rstd[pt]) + splat(L.nm[pt]);
-                    w[hf] = pk_bf16_relu(t * pair(G.v[ct][g], 2 * hf) + pair(E.v[ct][g], 2 * hf));
+                    y[hf] = t * pair(G.v[ct][g], 2 * hf) + pair(E.v[ct][g], 2 * hf);
                 }
-                *reinterpret_cast<uint2*>(g_smem + pixbase[pt] + chan32<CT>(wave, ct, g, h) * 2) = make_uint2(w[0], w[1]);
+                store4<P, true>(pixbase[pt], chan32<CT>(wave, ct, g, h), y[0], y[1]);
             }
 }
 // parameters already in registers (stem, heads)
@@ -303,17 +387,15 @@ __device__ inline void layernorm32(f32x16 (&acc)[CT][2], const ChP<CT>& G, const
 
 // accumulators -> bf16 image: pixbase[pt] = byte offset of the lane's pixel row inside g_smem, 4 adjacent channels
 // per 8-byte store
-template <int CT>
+template <class P, int CT>
 __device__ inline void store_image32(const f32x16 (&acc)[CT][2], const int (&pixbase)[2], int wave, int h) {
 #pragma unroll
     for (int ct = 0; ct < CT; ct++)
 #pragma unroll
         for (int pt = 0; pt < 2; pt++)
 #pragma unroll
-            for (int g = 0; g < 4; g++) {
-                *reinterpret_cast<uint2*>(g_smem + pixbase[pt] + chan32<CT>(wave, ct, g, h) * 2) =
-                    make_uint2(pk_bf16(pair(acc[ct][pt], 4 * g)), pk_bf16(pair(acc[ct][pt], 4 * g + 2)));
-            }
+            for (int g = 0; g < 4; g++)
+                store4<P, false>(pixbase[pt], chan32<CT>(wave, ct, g, h), pair(acc[ct][pt], 4 * g), pair(acc[ct][pt], 4 * g + 2));
 }
 
 // Halving butterfly over the 32 lanes of a half-wave (squeeze-excitation average pool).  Level LVL pairs every lane
@@ -359,35 +441,50 @@ __device__ __forceinline__ void pool_level(float (&v)[NV], int lane) {
 }
 
 // first RS-1 k-steps of a layer's weights into its ring, ahead of the conv_mma32<.., PRE = true> that consumes them
-template <int CT, int TILES, int RS>
-__device__ __forceinline__ void ring_fill(bf16x8 (&bq)[RS][CT], const bf16_t* __restrict__ Wp, int wave_u, int lane) {
+template <class P, int CT, int TILES, int RS>
+__device__ __forceinline__ void ring_fill(typename P::frag (&bq)[RS][CT], const bf16_t* __restrict__ Wp, int wave_u, int lane) {
+    constexpr int TB = 64 * P::FB;
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<bf16_t*>(Wp) + (size_t)wave_u * CT * 512, 0, 0x7fffffff, 0x00020000);
+        const_cast<bf16_t*>(Wp) + (size_t)wave_u * CT * (TB / 2), 0, 0x7fffffff, 0x00020000);
 #pragma unroll
     for (int st = 0; st < RS - 1; st++)
 #pragma unroll
-        for (int ct = 0; ct < CT; ct++) bq[st][ct] = wload(rsrc, lane * 16 + ct * 1024, st * TILES * 1024);
+        for (int ct = 0; ct < CT; ct++) bq[st][ct] = wload_p<P>(rsrc, lane * 16, ct, st * TILES * TB);
+}
+// E8M0 scale bytes of this wave's channel tiles for conv `conv_idx` (fp8): [conv][8 tiles][64 lanes] ints behind the
+// fp32 parameters (weights.hpp); requested one conv ahead of their use
+template <class P, int CT>
+__device__ __forceinline__ void scale_load(int (&sa)[CT], const NetDev& net, int conv_idx, int wave, int lane) {
+#pragma unroll
+    for (int ct = 0; ct < CT; ct++)
+        sa[ct] = P::FP8 ? __builtin_bit_cast(int, net.wf[net.f_scales + (size_t)((conv_idx * 8 + wave * CT + ct) * 64 + lane)]) : 127;
 }
 
+// (sized for the bf16 images; the fp8 instantiations use the same budget)
 constexpr int tower32_lds_bytes(int C) {
     const int xa = 100 * (C + 8) * 2;
     return xa + 64 * (HEAD + 8) * 2 + 4096 + 3072 + 1024 + 64 + 15 * C * 2;
 }
 
-template <int C, int RS, int TPI>
+// P: precision policy of the convs; AB: image-fragment buffers of the trunk convs; HRS / H2RS: ring slots of the head convs
+// (their rings hold a wave's whole weight stream).
+template <class P, int C, int RS, int TPI, int AB = SC_T32_AB>
 #ifndef SC_T32_OCC
 #define SC_T32_OCC 1
 #endif
 __global__ __launch_bounds__(256, SC_T32_OCC) void k_tower32(TowerArgs A) {
+    typedef typename P::frag frag;
     constexpr int CT = C / 128;        // 32-channel tiles per wave in the trunk
     constexpr int TILES = C / 32;
-    constexpr int CP = C + 8;          // image pixel stride (elements): (C+8)*2 B is an odd multiple of 16 B
-    constexpr int HP = HEAD + 8;
+    constexpr int PSB = pix_stride<P>(C);      // image pixel stride in bytes: an odd multiple of 16 B
+    constexpr int HPSB = pix_stride<P>(HEAD);
+    constexpr int EB = P::EB;
+    constexpr int HRS = P::FP8 ? C / 64 : 8, HAB = P::FP8 ? 2 : SC_T32_AB;         // 256-wide head convs (K = C)
+    constexpr int H2RS = P::FP8 ? HEAD / 64 : 16, H2AB = P::FP8 ? 2 : SC_T32_AB;   // the 73-wide one (K = 256)
     constexpr int NTW = C / 64;        // 16-column tiles per wave of the SE layers (16x16x32 vector products)
-    constexpr int XA_BYTES = 100 * CP * 2;
-    constexpr int RS_BYTES = 64 * HP * 2;   // the policy head's image
+    constexpr int XA_BYTES = (100 * PSB > 4864 * 4) ? 100 * PSB : 4864 * 4;   // image; later the 4672 policy logits
+    constexpr int RS_BYTES = 64 * HPSB;   // the policy head's image
     unsigned char* smem = g_smem;
-    bf16_t* Xa = reinterpret_cast<bf16_t*>(smem);                           // [100][CP] bf16 haloed image
     float* s_stat = reinterpret_cast<float*>(smem + XA_BYTES + RS_BYTES);   // 2 x [4][64] float2
     float* s_vec = s_stat + 1024;                                           // SE vectors (packed bf16)
     float* s_scl = s_vec + 768;                                             // [C] SE scales
@@ -412,10 +509,14 @@ __global__ __launch_bounds__(256, SC_T32_OCC) void k_tower32(TowerArgs A) {
     stampv.start();
 #endif
     const int bp[2] = {gpix2board(0, i32), gpix2board(1, i32)};            // this lane's two board pixels
-    const int pixbase[2] = {hidx(bp[0]) * CP * 2, hidx(bp[1]) * CP * 2};   // their rows in the haloed image (bytes)
-    const int px[2] = {pixbase[0] + h * 16, pixbase[1] + h * 16};          // + this lane's k half
+    const int pixbase[2] = {hidx(bp[0]) * PSB, hidx(bp[1]) * PSB};         // their rows in the haloed image (bytes)
+    const int px[2] = {pixbase[0] + h * P::FB, pixbase[1] + h * P::FB};    // + this lane's k half
 
-    bf16x8 ring[RS][CT];   // weight prefetch ring, carried from layer to layer
+    frag ring[RS][CT];     // weight prefetch ring, carried from layer to layer
+    int sa[CT], san[CT];   // fp8: E8M0 weight scales of the current / the next conv (conv index: 0 stem, 1 + 2b / 2 + 2b
+                           // the convs of block b, then value conv, policy conv1, policy conv2)
+    scale_load<P, CT>(sa, net, 0, wave, lane);
+    scale_load<P, CT>(san, net, net.n_blocks > 0 ? 1 : 1 + 2 * net.n_blocks, wave, lane);
     ChP<CT> Bn;            // bias of the NEXT conv (requested one epilogue early)
     constexpr int PAR0 = XA_BYTES + RS_BYTES + 4096 + 3072 + 1024 + 64;   // = PAR_OFF below
     // ---- Every global read of the prologue is issued first: the input planes (7 dwords per thread) and, cooperatively,
@@ -432,24 +533,28 @@ __global__ __launch_bounds__(256, SC_T32_OCC) void k_tower32(TowerArgs A) {
     f32x4 spv = f32x4{0.f, 0.f, 0.f, 0.f};
     if (tid < 3 * C / 4) spv = *reinterpret_cast<const f32x4*>(net.wf + net.f_stem + tid * 4);
     else if (tid < C) spv = *reinterpret_cast<const f32x4*>(net.wf + net.f_blocks + (tid - 3 * C / 4) * 4);
-    ring_fill<CT, TILES, RS>(ring, net.wb + net.o_stem, wave, lane);   // the stem's first weights too
+    ring_fill<P, CT, TILES, RS>(ring, net.wb + net.o_stem, wave, lane);   // the stem's first weights too
     __builtin_amdgcn_sched_barrier(0);
     // ---- zero the image (halo stays zero for the whole kernel), then write the 112 input planes
     {
-        uint4* z = reinterpret_cast<uint4*>(Xa);
-        for (int k = tid; k < 100 * CP * 2 / 16; k += 256) z[k] = make_uint4(0, 0, 0, 0);
+        uint4* z = reinterpret_cast<uint4*>(smem);
+        for (int k = tid; k < 100 * PSB / 16; k += 256) z[k] = make_uint4(0, 0, 0, 0);
     }
     __syncthreads();
     {
-        uint32_t* dst = reinterpret_cast<uint32_t*>(Xa + hidx(p_in) * CP + q_in * 28);   // 56-byte plane groups: 4-byte aligned
+        uint32_t* dst = reinterpret_cast<uint32_t*>(smem + hidx(p_in) * PSB + q_in * 28 * EB);   // 28-plane groups: 4-byte aligned
 #pragma unroll
         for (int k = 0; k < 7; k++) {
             const uint32_t w = win[k];
             float v[4];
 #pragma unroll
             for (int b = 0; b < 4; b++) v[b] = (float)(int8_t)((w >> (8 * b)) & 0xff);
-            dst[2 * k] = pk_bf16(f32x2{v[0], v[1]});
-            dst[2 * k + 1] = pk_bf16(f32x2{v[2], v[3]});
+            if constexpr (P::FP8) {
+                dst[k] = pk_fp8x4(v[0], v[1], v[2], v[3]);   // plane values are 0 / 1: exact
+            } else {
+                dst[2 * k] = pk_bf16(f32x2{v[0], v[1]});
+                dst[2 * k + 1] = pk_bf16(f32x2{v[2], v[3]});
+            }
         }
         if (tid < C) *reinterpret_cast<f32x4*>(g_smem + PAR0 + tid * 16) = spv;
     }
@@ -486,7 +591,7 @@ __global__ __launch_bounds__(256, SC_T32_OCC) void k_tower32(TowerArgs A) {
         acc_init<CT>(acc, Bn);
         const bf16_t* w0 = net.wb + net.o_stem;
         SC_MARK(33);
-        conv_mma32<128, 9, CT, TILES, CP, RS, TPI, true>(0, w0, wave, lane, px, acc, ring, (int)((net.wb + net.o_blocks) - w0) * 2);
+        conv_mma32<P, 128, 9, CT, TILES, PSB, RS, TPI, true, AB>(0, w0, wave, lane, px, acc, ring, (int)((net.wb + net.o_blocks) - w0) * 2, sa);
         ChP<CT> G, E;
         ch_load_lds<CT>(G, PAR0 + C * 4, wave, h);
         ch_load_lds<CT>(E, PAR0 + 2 * C * 4, wave, h);
@@ -496,10 +601,11 @@ __global__ __launch_bounds__(256, SC_T32_OCC) void k_tower32(TowerArgs A) {
         SC_MARK(37);
     }
     store_res();
-    store_image32<CT>(acc, pixbase, wave, h);  // every wave passed the LN barrier: the input image is dead
+    store_image32<P, CT>(acc, pixbase, wave, h);  // every wave passed the LN barrier: the input image is dead
     __syncthreads();
     SC_MARK(14);
     dump(0);
+    const int head_conv0 = 1 + 2 * net.n_blocks;   // conv index of the value conv
 
     // ---- residual tower (ResBlockSE.forward, py/module.py:38-46)
 #pragma unroll 1
@@ -527,7 +633,10 @@ __global__ __launch_bounds__(256, SC_T32_OCC) void k_tower32(TowerArgs A) {
         __builtin_amdgcn_sched_barrier(0);
         // conv1 -> LN -> ReLU
         acc_init<CT>(acc, Bn);
-        conv_mma32<C, 9, CT, TILES, CP, RS, TPI, true>(0, wb, wave, lane, px, acc, ring, 9 * C * C * 2);
+#pragma unroll
+        for (int ct = 0; ct < CT; ct++) sa[ct] = san[ct];
+        scale_load<P, CT>(san, net, 2 + 2 * b, wave, lane);
+        conv_mma32<P, C, 9, CT, TILES, PSB, RS, TPI, true, AB>(0, wb, wave, lane, px, acc, ring, 9 * C * C * EB, sa);
         SC_MARK(0);
 #pragma unroll
         for (int k = 0; k < NPV; k++)
@@ -539,7 +648,7 @@ __global__ __launch_bounds__(256, SC_T32_OCC) void k_tower32(TowerArgs A) {
             ch_load_lds<CT>(G, P_G1, wave, h);
             ch_load_lds<CT>(E, P_E1, wave, h);
             SC_MARK(3);
-            ln_apply_relu_store<CT>(acc, L, G, E, pixbase, wave, h);
+            ln_apply_relu_store<P, CT>(acc, L, G, E, pixbase, wave, h);
         }
         ch_load_lds<CT>(Bn, P_B2, wave, h);
         __syncthreads();
@@ -548,8 +657,11 @@ __global__ __launch_bounds__(256, SC_T32_OCC) void k_tower32(TowerArgs A) {
         acc_init<CT>(acc, Bn);
         {
             // the loop's last prefetches fetch the first k-steps of the NEXT block's conv1 (or wrap on the last block)
-            const int nxt = (b + 1 < net.n_blocks) ? (int)(net.blk_stride_b - (size_t)9 * C * C) * 2 : 0;
-            conv_mma32<C, 9, CT, TILES, CP, RS, TPI, true>(0, wb + (size_t)9 * C * C, wave, lane, px, acc, ring, nxt);
+            const int nxt = (b + 1 < net.n_blocks) ? (int)(net.blk_stride_b * 2 - (size_t)9 * C * C * EB) : 0;
+#pragma unroll
+            for (int ct = 0; ct < CT; ct++) sa[ct] = san[ct];
+            scale_load<P, CT>(san, net, b + 1 < net.n_blocks ? 3 + 2 * b : head_conv0, wave, lane);   // (heads reload theirs: two tiles per wave)
+            conv_mma32<P, C, 9, CT, TILES, PSB, RS, TPI, true, AB>(0, wb + (size_t)9 * C * C * EB / 2, wave, lane, px, acc, ring, nxt, sa);
         }
         SC_MARK(5);
         // squeeze-excitation weights are requested now: their L2 round trip hides under the LayerNorm (issuing them
@@ -557,8 +669,8 @@ __global__ __launch_bounds__(256, SC_T32_OCC) void k_tower32(TowerArgs A) {
         // columns of both layers are split over the 4 waves.
         VecW<C, NTW1> w1;
         VecW<C / 2, NTW> w2;
-        vec_w_load<C, NTW1, NT1>(w1, wb + (size_t)18 * C * C, wave * NTW1, lane);
-        vec_w_load<C / 2, NTW, C / 16>(w2, wb + (size_t)18 * C * C + (size_t)C * (C / 2), wave * NTW, lane);
+        vec_w_load<C, NTW1, NT1>(w1, wb + (size_t)9 * C * C * EB, wave * NTW1, lane);
+        vec_w_load<C / 2, NTW, C / 16>(w2, wb + (size_t)9 * C * C * EB + (size_t)C * (C / 2), wave * NTW, lane);
         __builtin_amdgcn_sched_barrier(0);
         {
             LnStat L;
@@ -647,7 +759,7 @@ __global__ __launch_bounds__(256, SC_T32_OCC) void k_tower32(TowerArgs A) {
                 }
             }
         store_res();
-        store_image32<CT>(acc, pixbase, wave, h);  // conv2 finished reading Xa before the SE barriers
+        store_image32<P, CT>(acc, pixbase, wave, h);  // conv2 finished reading Xa before the SE barriers
         ch_load_lds<CT>(Bn, P_BN, wave, h);        // next block's conv1 bias: read before the barrier that frees the staging area
         SC_MARK(12);
         __syncthreads();
@@ -659,7 +771,7 @@ __global__ __launch_bounds__(256, SC_T32_OCC) void k_tower32(TowerArgs A) {
     stampv.start();
 #endif
 
-    const int gpb[2] = {(i32 * HP) * 2, ((32 + i32) * HP) * 2};   // rows of the plain (non-haloed) policy image
+    const int gpb[2] = {i32 * HPSB, (32 + i32) * HPSB};   // rows of the plain (non-haloed) policy image
     // The three heads' per-channel parameters (1920 contiguous floats) are fetched cooperatively under the value
     // conv and staged in LDS (the SE scratch is dead now), like the per-block parameters of the trunk.
     constexpr int HPAR = XA_BYTES + RS_BYTES + 4096;            // byte offset of the staging area (s_vec ...)
@@ -672,8 +784,10 @@ __global__ __launch_bounds__(256, SC_T32_OCC) void k_tower32(TowerArgs A) {
     __builtin_amdgcn_sched_barrier(0);
     // The 1x1 head convs are short (8 or 16 k-steps): their rings hold the WHOLE weight stream of a wave (a 3-step
     // prefetch distance is 200-400 MFMA cycles, less than the L2 latency: every k-step stalled, 35 % matrix rate).
-    bf16x8 hr[8][2];      // weight ring of the 256-wide head convs (value conv -> policy conv1 carry)
-    bf16x8 hr2[16][1];    // ... of the 73-wide one
+    frag hr[HRS][2];      // weight ring of the 256-wide head convs (value conv -> policy conv1 carry)
+    frag hr2[H2RS][1];    // ... of the 73-wide one
+    int sh[2], sh2[1];    // fp8 weight scales of the head convs
+    scale_load<P, 2>(sh, net, head_conv0, wave, lane);
     // ---- value head conv (py/module.py:89-94): conv1x1 C->256, LN, ReLU -> bf16 features in HBM
     {
         f32x16 hv[2][2];
@@ -683,8 +797,10 @@ __global__ __launch_bounds__(256, SC_T32_OCC) void k_tower32(TowerArgs A) {
             for (int pt = 0; pt < 2; pt++)
 #pragma unroll
                 for (int r = 0; r < 16; r++) hv[ct][pt][r] = 0.f;
-        conv_mma32<C, 1, 2, 8, CP, 8, 1, false>(0, net.wb + net.o_vconv, wave, lane, px, hv, hr,
-                                                (int)((net.wb + net.o_pconv1) - (net.wb + net.o_vconv)) * 2);
+        conv_mma32<P, C, 1, 2, 8, PSB, HRS, 1, false, HAB>(0, net.wb + net.o_vconv, wave, lane, px, hv, hr,
+                                                           (int)((net.wb + net.o_pconv1) - (net.wb + net.o_vconv)) * 2, sh);
+        scale_load<P, 2>(sh, net, head_conv0 + 1, wave, lane);
+        scale_load<P, 1>(sh2, net, head_conv0 + 2, wave, lane);
         SC_MARK(20);
 #pragma unroll
         for (int k = 0; k < 2; k++)
@@ -726,9 +842,9 @@ __global__ __launch_bounds__(256, SC_T32_OCC) void k_tower32(TowerArgs A) {
         ch_load_lds<2>(Bv, HP_P1, wave, h);
         f32x16 hp[2][2];
         acc_init<2>(hp, Bv);
-        conv_mma32<C, 1, 2, 8, CP, 8, 1, true>(0, net.wb + net.o_pconv1, wave, lane, px, hp, hr, 0);
+        conv_mma32<P, C, 1, 2, 8, PSB, HRS, 1, true, HAB>(0, net.wb + net.o_pconv1, wave, lane, px, hp, hr, 0, sh);
         SC_MARK(24);
-        ring_fill<1, 4, 16>(hr2, net.wb + net.o_pconv2, wave, lane);   // hidden under the LayerNorm
+        ring_fill<P, 1, 4, H2RS>(hr2, net.wb + net.o_pconv2, wave, lane);   // hidden under the LayerNorm
         __builtin_amdgcn_sched_barrier(0);
         LnStat L;
         ln_reduce<2>(hp, L, HEAD, wave, lane, s_stat, ln_parity, bad SC_STAMP_PASS(25));
@@ -736,7 +852,7 @@ __global__ __launch_bounds__(256, SC_T32_OCC) void k_tower32(TowerArgs A) {
         ch_load_lds<2>(E, HP_P1 + 2 * HEAD * 4, wave, h);
         ln_apply<2>(hp, L, G, E, false);
         const int xb[2] = {XA_BYTES + gpb[0], XA_BYTES + gpb[1]};
-        store_image32<2>(hp, xb, wave, h);   // Xh: the head image behind Xa
+        store_image32<P, 2>(hp, xb, wave, h);   // Xh: the head image behind Xa
         SC_MARK(27);
     }
     __syncthreads();
@@ -746,8 +862,8 @@ __global__ __launch_bounds__(256, SC_T32_OCC) void k_tower32(TowerArgs A) {
         ch_load_lds<1>(Bv, HP_P2, wave, h);
         f32x16 z[1][2];
         acc_init<1>(z, Bv);
-        const int pxh[2] = {gpb[0] + h * 16, gpb[1] + h * 16};
-        conv_mma32<HEAD, 1, 1, 4, HP, 16, 1, true>(XA_BYTES, net.wb + net.o_pconv2, wave, lane, pxh, z, hr2, 0);
+        const int pxh[2] = {gpb[0] + h * P::FB, gpb[1] + h * P::FB};
+        conv_mma32<P, HEAD, 1, 1, 4, HPSB, H2RS, 1, true, H2AB>(XA_BYTES, net.wb + net.o_pconv2, wave, lane, pxh, z, hr2, 0, sh2);
         SC_MARK(28);
         // padded channels (>=73) have zero weights, bias, gamma, beta: they add 0 to both LN sums
         LnStat L;

@@ -11,7 +11,7 @@
 // Same flags, same defaults; `-t` may contain `{}` (replaced by the 1-based game number, run_batch's
 // JOB_ID) -- without it and with --games 1 the file name is used verbatim, exactly like the reference.
 // Extra flags (no reference counterpart): --games, --concurrency, --groups, --gpus, --seed, --blocks/--channels
-// (random-init network when no checkpoint is given), --first-game.
+// (random-init network when no checkpoint is given), --first-game, --fp8 (e4m3 convs; BASELINE configs[4]).
 // One host thread per GPU; games are sharded statically over GPUs, no collective.
 // Traces stream out: each game's file is written when the game ends (the reference saves at the end of its one game,
 // src/main.rs:235-238), from a bounded ring of traces on the device (sc_selfplay_poll), whatever --games is.
@@ -39,6 +39,7 @@ struct Args {
     float epsilon = 0.15f;
     // extensions
     int games = 1, concurrency = 256, gpus = 1, blocks = 10, channels = 256;
+    bool fp8 = false;  // --fp8: run the convs in e4m3 (an SCW2 checkpoint selects it by itself)
     int groups = 1;  // handles per GPU on separate HIP streams: one group's tree work hides under another's network launch
                      // (e.g. --concurrency 512 --groups 2: +28 % simulations/s on one MI355X)
     unsigned long long seed = 0xC0FFEEULL, first_game = 0;
@@ -48,7 +49,7 @@ static void usage() {
     fprintf(stderr,
             "usage: sc-selfplay [-d cuda] [-r|--rollout-factor F | --rollout-num N] [-n|--num-steps 100] [-t|--trace-file trace.json]\n"
             "                   [-c|--checkpoint weights.scw] [--temperature 0] [--cpuct 1] [--temperature-switch 30] [--epsilon 0.15]\n"
-            "                   [--games 1] [--concurrency 256] [--groups 1] [--gpus 1] [--seed S] [--first-game K] [--blocks 10] [--channels 256]\n");
+            "                   [--games 1] [--concurrency 256] [--groups 1] [--gpus 1] [--seed S] [--first-game K] [--blocks 10] [--channels 256] [--fp8]\n");
 }
 
 static bool parse(int argc, char** argv, Args& a) {
@@ -80,6 +81,7 @@ static bool parse(int argc, char** argv, Args& a) {
         else if (k == "--first-game") a.first_game = strtoull(val("first-game"), nullptr, 0);
         else if (k == "--blocks") a.blocks = atoi(val("blocks"));
         else if (k == "--channels") a.channels = atoi(val("channels"));
+        else if (k == "--fp8") a.fp8 = true;
         else if (k == "-h" || k == "--help") { usage(); exit(0); }
         else { fprintf(stderr, "unknown argument %s\n", k.c_str()); usage(); return false; }
     }
@@ -98,7 +100,7 @@ static std::string trace_name(const Args& a, unsigned long long game_number) {
 
 static int run_gpu(const Args& a, int gpu, int first, int count, int* finished_with_outcome) {
     sc_engine* eng = nullptr;
-    sc_net_config nc{a.blocks, a.channels, a.seed};
+    sc_net_config nc{a.blocks, a.channels, a.seed, a.fp8 ? SC_PREC_FP8 : SC_PREC_BF16, 0};
     const char* w = a.checkpoint == "__no_checkpoint__" ? nullptr : a.checkpoint.c_str();
     if (sc_engine_create(&nc, w, gpu, &eng)) {
         fprintf(stderr, "gpu %d: %s\n", gpu, sc_last_error());

@@ -23,7 +23,8 @@ class EngineError(RuntimeError):
 
 
 class NetConfig(C.Structure):
-    _fields_ = [("n_res_blocks", C.c_int32), ("channels", C.c_int32), ("seed", C.c_uint64)]
+    _fields_ = [("n_res_blocks", C.c_int32), ("channels", C.c_int32), ("seed", C.c_uint64), ("precision", C.c_int32),
+                ("reserved", C.c_int32)]
 
 
 class SelfplayConfig(C.Structure):
@@ -58,6 +59,7 @@ ABI = {
     "sc_engine_create": (_i, [C.POINTER(NetConfig), C.c_char_p, _i, C.POINTER(_vp)]),
     "sc_engine_destroy": (None, [_vp]),
     "sc_engine_max_batch": (_i, [_vp]),
+    "sc_engine_precision": (_i, [_vp]),
     "sc_forward_batch": (_i, [_vp, _i, _vp, _vp, _vp, _vp]),
     "sc_predict_batch": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sc_predict_batch_device": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -141,13 +143,14 @@ def uci_move(s):
 class Engine:
     """The network backend (replaces ChessTS/ChessEP/ChessOnnx construction, src/main.rs:83-128)."""
 
-    def __init__(self, n_res_blocks=10, channels=256, seed=0, weights=None, device=0):
+    def __init__(self, n_res_blocks=10, channels=256, seed=0, weights=None, device=0, precision="bf16"):
         self.L = lib()
         self.n_res_blocks, self.channels = n_res_blocks, channels
-        cfg = NetConfig(n_res_blocks, channels, seed)
+        cfg = NetConfig(n_res_blocks, channels, seed, {"bf16": 0, "fp8": 1}[precision], 0)
         h = C.c_void_p()
         _check(self.L.sc_engine_create(C.byref(cfg), weights.encode() if weights else None, device, C.byref(h)))
         self.h = h
+        self.precision = "fp8" if self.L.sc_engine_precision(h) == 1 else "bf16"   # an SCW2 blob decides by itself
 
     def close(self):
         if getattr(self, "h", None):
