@@ -32,6 +32,7 @@ sys.path.insert(0, os.path.join(ROOT, "smart-chess-rust_amd"))
 sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0  # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md, chip-level parameters)
+PEAK_FP8_TFLOPS = 5000.0   # dense fp8 (block-scaled e4m3) MFMA peak, same table
 HBM_PEAK_GBS = 8000.0
 
 
@@ -65,6 +66,12 @@ def cpu_baseline(n_blocks, C, budget_s, rollout):
     # dockerfile:14 OMP_NUM_THREADS=1 + scripts/run_batch's `parallel -j`)
     total_cores = os.cpu_count() or 1
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else total_cores
+    try:   # a container's CPU quota (cgroup v2 cpu.max) is the real share: more threads than that only time-slice
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            cores = min(cores, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
     cores = max(1, cores)
     net = orc.Net(n_blocks, C, seed=1)
     ev = orc.eval_fn("orc_eval_net")
@@ -121,9 +128,12 @@ def run_gpu(args, rank, world, local_rank):
     runs = [("main", args.channels, args.games, max(1, args.groups))]
     if args.alt and world == 1:
         runs += [("steady", args.channels, args.games, 1),
-                 ("alt", 256 if args.channels == 128 else 128, args.games, max(1, args.groups)), ("x2", args.channels, 2 * args.games, 2)]
+                 ("alt", 256 if args.channels == 128 else 128, args.games, max(1, args.groups)), ("x2", args.channels, 2 * args.games, 2),
+                 # BASELINE configs[4]: fp8 (e4m3) network, 4096 games over 8 GPUs = 512 per GPU; and at the headline's 256
+                 ("fp8", args.channels, args.games, 1), ("fp8_512", args.channels, 2 * args.games, 1)]
     for tag, C, G, K in runs:
-        eng = scamd.Engine(args.blocks, C, seed=1, device=local_rank)
+        prec = "fp8" if tag.startswith("fp8") else args.precision
+        eng = scamd.Engine(args.blocks, C, seed=1, device=local_rank, precision=prec)
         assert G % K == 0
         sps = [scamd.SelfPlay(eng, n_slots=G // K, n_games=10 ** 7 // K, trace_capacity=4 * G // K, rollout_num=R, num_steps=150,
                               cpuct=2.5, temperature=0.0, temperature_switch=4, epsilon=0.15, with_noise=True, seed=1234,
@@ -173,7 +183,7 @@ def run_gpu(args, rank, world, local_rank):
         tms = [sp.timing() for sp in sps]
         s1 = stats()
         nl = sum(t["tower_launches"] for t in tms)
-        res[tag] = dict(C=C, regions=regions, steps=steps, nn_evals=s1["nn_evals"] - nn0["nn_evals"],
+        res[tag] = dict(C=C, precision=prec, regions=regions, steps=steps, nn_evals=s1["nn_evals"] - nn0["nn_evals"],
                         sims_all=s1["sims_done"] - nn0["sims_done"], err=s1["error_flags"],
                         tower_ms=sum(t["ms_tower_sum"] for t in tms) / max(nl, 1), tower_launches=nl,
                         span_ms=max(t["ms_total"] for t in tms), groups=K, games=G)
@@ -229,7 +239,8 @@ def main():
     ap.add_argument("--rollout", type=int, default=180)
     ap.add_argument("--blocks", type=int, default=10)
     ap.add_argument("--channels", type=int, default=128, help="trunk width: 128 = BASELINE configs[1]; 256 = reference module")
-    ap.add_argument("--no-alt", dest="alt", action="store_false", help="skip the short run of the other trunk width")
+    ap.add_argument("--no-alt", dest="alt", action="store_false", help="skip the short extra runs (steady state, other width, 2x games, fp8)")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp8"], help="network precision of the main run (BASELINE configs[1]: bf16)")
     ap.add_argument("--groups", type=int, default=1, help="split the games of a GPU into K groups on K HIP streams (overlap)")
     ap.add_argument("--timing-stride", type=int, default=8,
                     help="every n-th tower launch is bracketed by a HIP event pair for the roofline figure (an event pair per "
@@ -324,11 +335,11 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "bf16",
+            "dtype": m.get("precision", "bf16"),
             "data": "synthetic" if not args.cpu_dry_run else "cpu-dry-run (oracle stand-in; harness test only)",
             "config": {
                 "workload": (f"BASELINE configs[1]: {args.games} concurrent self-play games per GPU from the start position, "
-                             f"rollout={args.rollout}, {args.blocks}-block/{m['C']}-ch SE-ResNet bf16 (random-init), "
+                             f"rollout={args.rollout}, {args.blocks}-block/{m['C']}-ch SE-ResNet {m.get('precision', 'bf16')} (random-init), "
                              "cpuct 2.5, Dirichlet(0.3) eps 0.15, temperature switch 4"),
                 "games_per_gpu": args.games, "rollout": args.rollout, "net": f"{args.blocks}x{m['C']}",
                 "step": "one ply = rollout simulation steps over all games", "parallelism": f"games sharded over {world} GPU(s), no collective",
@@ -338,13 +349,14 @@ def main():
         if not args.cpu_dry_run:
             pos_per_launch = args.games // m.get("groups", 1)
             tf = pos_per_launch * flop_tower / (m["tower_ms"] * 1e-3) / 1e12 if m["tower_ms"] > 0 else 0.0
+            peak = PEAK_FP8_TFLOPS if m.get("precision") == "fp8" else PEAK_BF16_TFLOPS
             out["roofline"] = {
-                "bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(tf / PEAK_BF16_TFLOPS, 4), "traffic": load_traffic(m["C"]),
-                "kernel": f"k_tower32<{m['C']}>", "avg_launch_ms": round(m["tower_ms"], 4), "launches_timed": m["tower_launches"],
+                "bound": "mfma", "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s",
+                "frac": round(tf / peak, 4), "traffic": load_traffic(m["C"]),
+                "kernel": f"k_tower32<{m.get('precision', 'bf16')}, {m['C']}>", "avg_launch_ms": round(m["tower_ms"], 4), "launches_timed": m["tower_launches"],
                 "flop_per_launch": pos_per_launch * flop_tower, "positions_per_launch": pos_per_launch, "concurrent_groups": m.get("groups", 1),
                 "flop_note": "the tower launch's own layers (stem, blocks, head convs); value_head.ffn runs in k_value_fc1 / the search kernel",
-                "end_to_end_frac": round(sims / seconds / world * flop_pos / (PEAK_BF16_TFLOPS * 1e12), 4),
+                "end_to_end_frac": round(sims / seconds / world * flop_pos / (peak * 1e12), 4),
             }
             out["nn_evals_per_sim"] = round(m["nn_evals"] / max(m["sims_all"], 1), 4)
             out["error_flags"] = m["err"]
@@ -363,6 +375,22 @@ def main():
                                "tower_avg_ms": round(a["tower_ms"], 4),
                                "roofline_frac": round(args.games * fa / (a["tower_ms"] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4)
                                if a["tower_ms"] > 0 else None}
+            for tag in ("fp8", "fp8_512"):
+                if tag in res:
+                    x = res[tag]
+                    v, ms = rate(x)
+                    f8 = 2.0 * macs_per_position(args.blocks, x["C"], tower_only=True)
+                    tf8 = x["games"] * f8 / (x["tower_ms"] * 1e-3) / 1e12 if x["tower_ms"] > 0 else 0.0
+                    out["also_" + tag] = {
+                        "config": ("BASELINE configs[4] sizing: fp8 (OCP e4m3) policy/value net on the CDNA4 fp8 matrix cores, "
+                                   f"{x['games']} concurrent games per GPU" + ("" if tag == "fp8_512" else " (the headline's game count)")),
+                        "dtype": "fp8", "games_per_gpu": x["games"], "net": f"{args.blocks}x{x['C']}", "value": round(v, 1), "ms_per_step": round(ms, 3),
+                        "error_flags": x["err"],
+                        "roofline": {"bound": "mfma", "achieved": round(tf8, 2), "peak": PEAK_FP8_TFLOPS, "unit": "TFLOP/s",
+                                     "frac": round(tf8 / PEAK_FP8_TFLOPS, 4), "kernel": f"k_tower32<fp8, {x['C']}>",
+                                     "avg_launch_ms": round(x["tower_ms"], 4), "launches_timed": x["tower_launches"],
+                                     "flop_per_launch": x["games"] * f8, "positions_per_launch": x["games"],
+                                     "end_to_end_frac": round(v * 2.0 * macs_per_position(args.blocks, x["C"]) / (PEAK_FP8_TFLOPS * 1e12), 4)}}
             if "x2" in res:
                 x = res["x2"]
                 v, ms = rate(x)

@@ -7,6 +7,8 @@ and every key loses its first dotted component, e.g. `model.`).  The file is rea
 from the tensors (`res_blocks.<i>.*`, `conv_block.0.weight`).
 
     python tools/ckpt_to_scw.py last.ckpt last.scw      ->   sc-selfplay -c last.scw ... / scamd.Engine(weights="last.scw")
+    python tools/ckpt_to_scw.py --fp8 last.ckpt last8.scw   the fp8 export (SCW2: e4m3 conv weights + one power-of-two scale per
+                                                            output channel, tools/scw.py); the engine then runs its fp8 tower
 """
 import os
 import re
@@ -36,7 +38,7 @@ def infer_shape(sd):
     return n_blocks, C
 
 
-def convert(src, dst):
+def convert(src, dst, fp8=False):
     import torch
     obj = torch.load(src, map_location="cpu", weights_only=True)
     sd = state_dict_from_checkpoint(obj)
@@ -46,12 +48,13 @@ def convert(src, dst):
     missing = sorted(names - set(sd))
     if missing:
         raise ValueError(f"checkpoint lacks {len(missing)} tensors, e.g. {missing[:3]}")
-    scw.write_scw(dst, sd, n_blocks, C)
+    scw.write_scw(dst, sd, n_blocks, C, fp8=fp8)
     return n_blocks, C, sorted(set(sd) - names)
 
 
 if __name__ == "__main__":
-    if len(sys.argv) != 3:
+    args = [a for a in sys.argv[1:] if a != "--fp8"]
+    if len(args) != 2:
         raise SystemExit(__doc__)
-    nb, C, extra = convert(sys.argv[1], sys.argv[2])
-    print(f"{sys.argv[2]}: {nb} blocks x {C} channels" + (f"; ignored keys: {extra[:5]}" if extra else ""))
+    nb, C, extra = convert(args[0], args[1], fp8="--fp8" in sys.argv)
+    print(f"{args[1]}: {nb} blocks x {C} channels" + (" (fp8 export)" if "--fp8" in sys.argv else "") + (f"; ignored keys: {extra[:5]}" if extra else ""))
