@@ -352,7 +352,7 @@ def main():
             peak = PEAK_FP8_TFLOPS if m.get("precision") == "fp8" else PEAK_BF16_TFLOPS
             out["roofline"] = {
                 "bound": "mfma", "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s",
-                "frac": round(tf / peak, 4), "traffic": load_traffic(m["C"]),
+                "frac": round(tf / peak, 4), "traffic": load_traffic(m["C"], m.get("precision", "bf16")),
                 "kernel": f"k_tower32<{m.get('precision', 'bf16')}, {m['C']}>", "avg_launch_ms": round(m["tower_ms"], 4), "launches_timed": m["tower_launches"],
                 "flop_per_launch": pos_per_launch * flop_tower, "positions_per_launch": pos_per_launch, "concurrent_groups": m.get("groups", 1),
                 "flop_note": "the tower launch's own layers (stem, blocks, head convs); value_head.ffn runs in k_value_fc1 / the search kernel",
@@ -405,11 +405,11 @@ def main():
         _dist.destroy_process_group()
 
 
-def load_traffic(C):
+def load_traffic(C, precision="bf16"):
     """HBM bytes per tower launch from the rocprofv3 PMC passes committed under profiles/ (null if not collected)"""
     p = os.path.join(ROOT, "profiles", "traffic.json")
     try:
-        return json.load(open(p)).get(f"k_tower32<{C}>")
+        return json.load(open(p)).get(f"k_tower32<{C}>" if precision == "bf16" else f"k_tower32<{precision},{C}>")
     except Exception:
         return None
 

@@ -30,7 +30,7 @@ def per_kernel(counter_csv, counter):
     return {k: (v[0] / v[1], v[1]) for k, v in acc.items()}
 
 
-def main(tag, ch):
+def main(tag, ch, key=None):
     src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
     dst = os.path.join(ROOT, "profiles")
     os.makedirs(dst, exist_ok=True)
@@ -52,7 +52,7 @@ def main(tag, ch):
         by = fk[0] * 1024 * 2 + wk[0] * 1024
         rows.append((k, fk[1], fk[0], wk[0], by))
         if "k_tower" in k:
-            traffic[f"k_tower32<{ch}>"] = round(by)
+            traffic[key or f"k_tower32<{ch}>"] = round(by)
     with open(os.path.join(dst, f"{tag}_c{ch}_pmc_hbm.csv"), "w") as f:
         f.write("kernel,launches,avg_FETCH_SIZE_KiB,avg_WRITE_SIZE_KiB,hbm_bytes_per_launch(2*FETCH+WRITE)*1024\n")
         for r in rows:
@@ -63,4 +63,6 @@ def main(tag, ch):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1] if len(sys.argv) > 1 else "r01", sys.argv[2] if len(sys.argv) > 2 else "128")
+    # optional 3rd argument: key of the tower kernel in profiles/traffic.json (default k_tower32<ch>; the fp8 passes use
+    # k_tower32<fp8,ch>, which is what bench.py looks up for an fp8 run)
+    main(sys.argv[1] if len(sys.argv) > 1 else "r01", sys.argv[2] if len(sys.argv) > 2 else "128", sys.argv[3] if len(sys.argv) > 3 else None)
