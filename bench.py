@@ -338,7 +338,7 @@ def main():
             "dtype": m.get("precision", "bf16"),
             "data": "synthetic" if not args.cpu_dry_run else "cpu-dry-run (oracle stand-in; harness test only)",
             "config": {
-                "workload": (f"BASELINE configs[1]: {args.games} concurrent self-play games per GPU from the start position, "
+                "workload": (f"{config_name(args, m)}: {args.games} concurrent self-play games per GPU from the start position, "
                              f"rollout={args.rollout}, {args.blocks}-block/{m['C']}-ch SE-ResNet {m.get('precision', 'bf16')} (random-init), "
                              "cpuct 2.5, Dirichlet(0.3) eps 0.15, temperature switch 4"),
                 "games_per_gpu": args.games, "rollout": args.rollout, "net": f"{args.blocks}x{m['C']}",
@@ -403,6 +403,18 @@ def main():
     if _dist is not None:
         _dist.barrier()
         _dist.destroy_process_group()
+
+
+def config_name(args, m):
+    """which BASELINE.json configuration the arguments are"""
+    prec = m.get("precision", "bf16")
+    if (args.games, args.rollout, args.blocks, m["C"], prec) == (256, 180, 10, 128, "bf16"):
+        return "BASELINE configs[1]"
+    if (args.games, args.rollout, args.blocks, m["C"], prec) == (256, 800, 20, 256, "bf16"):
+        return "BASELINE configs[3], per-GPU slice (20x256, rollout 800)"
+    if prec == "fp8":
+        return "BASELINE configs[4] variant (fp8 network)"
+    return "custom configuration"
 
 
 def load_traffic(C, precision="bf16"):
