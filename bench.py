@@ -130,10 +130,16 @@ def run_gpu(args, rank, world, local_rank):
         runs += [("steady", args.channels, args.games, 1),
                  ("alt", 256 if args.channels == 128 else 128, args.games, max(1, args.groups)), ("x2", args.channels, 2 * args.games, 2),
                  # BASELINE configs[4]: fp8 (e4m3) network, 4096 games over 8 GPUs = 512 per GPU; and at the headline's 256
-                 ("fp8", args.channels, args.games, 1), ("fp8_512", args.channels, 2 * args.games, 1)]
+                 ("fp8", args.channels, args.games, 1), ("fp8_512", args.channels, 2 * args.games, 1),
+                 # a random-init net has nearly flat priors (shallow trees); a trained one is sharp.  Same weights with the
+                 # policy head's last LayerNorm gain x 8: the search descends deeper, the network cost is unchanged
+                 ("sharp", args.channels, args.games, 1)]
     for tag, C, G, K in runs:
         prec = "fp8" if tag.startswith("fp8") else args.precision
-        eng = scamd.Engine(args.blocks, C, seed=1, device=local_rank, precision=prec)
+        if tag == "sharp":
+            eng = sharp_prior_engine(scamd, args.blocks, C, local_rank, prec)
+        else:
+            eng = scamd.Engine(args.blocks, C, seed=1, device=local_rank, precision=prec)
         assert G % K == 0
         sps = [scamd.SelfPlay(eng, n_slots=G // K, n_games=10 ** 7 // K, trace_capacity=4 * G // K, rollout_num=R, num_steps=150,
                               cpuct=2.5, temperature=0.0, temperature_switch=4, epsilon=0.15, with_noise=True, seed=1234,
@@ -190,10 +196,30 @@ def run_gpu(args, rank, world, local_rank):
         if tag == "steady":
             plies = [sps[0].slot(g)["ply"] for g in range(0, G, 8)]
             res[tag]["ply_min_max"] = (min(plies), max(plies))
+        if tag in ("main", "sharp", "steady"):   # tree levels walked by the last descent of a sample of games
+            lens = [len(sps[0].slot(g)["path"]) for g in range(0, G, 4)]
+            res[tag]["mean_path_len"] = sum(lens) / len(lens)
         for sp in sps:
             sp.close()
         eng.close()
     return res
+
+
+def sharp_prior_engine(scamd, n_blocks, C, device, precision):
+    """the seed-1 network with policy_head.model.3.weight (the gain of the policy head's last LayerNorm) multiplied by 8:
+    logits 8x larger, priors concentrated on a few moves like a trained network's"""
+    import tempfile
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import scw
+    sd = scw.prng_state_dict(n_blocks, C, seed=1)
+    sd["policy_head.model.3.weight"] = sd["policy_head.model.3.weight"] * 8.0
+    with tempfile.NamedTemporaryFile(suffix=".scw", delete=False) as f:
+        path = f.name
+    try:
+        scw.write_scw(path, sd, n_blocks, C)
+        return scamd.Engine(weights=path, device=device, precision=precision)
+    finally:
+        os.unlink(path)
 
 
 def seed_mid_game_positions(scamd, eng, sp, G, R):
@@ -367,6 +393,13 @@ def main():
                                       "nn_evals_per_sim": round(st["nn_evals"] / max(st["sims_all"], 1), 4), "error_flags": st["err"],
                                       "note": ("same configuration, but the slots hold games at every stage: slot g starts from the first "
                                                "g*150/G plies of a pre-played game (mid-game branching factors, full 8-board histories)")}
+            if "sharp" in res:
+                st = res["sharp"]
+                v, ms = rate(st)
+                out["also_sharp_priors"] = {"value": round(v, 1), "ms_per_step": round(ms, 3), "mean_path_len": round(st["mean_path_len"], 2),
+                                            "mean_path_len_main": round(m.get("mean_path_len", 0.0), 2), "error_flags": st["err"],
+                                            "note": ("same network with the policy head's last LayerNorm gain x 8 (priors concentrated like a trained "
+                                                     "net's): deeper descents, same network cost")}
             if "alt" in res:
                 a = res["alt"]
                 fa = 2.0 * macs_per_position(args.blocks, a["C"], tower_only=True)
