@@ -617,16 +617,20 @@ __global__ __launch_bounds__(64) void k_synth_eval(SpParams p) {
 }
 
 // ------------------------------------------------------------------ game (re)start
-// Game ordinal k (0-based on this handle) takes trace-ring row k % trace_cap.  The row may still belong to another game:
-// a LIVE one (a long game next to slots that cycle through short ones can be lapped: writing its rows would corrupt both
-// traces), or -- with trace_hold -- a finished one the host has not released yet (sc_selfplay_poll).  Then the slot
-// waits (ST_PENDING, its ordinal parked in game_id) and retries at every simulation step.
+// Game ordinal k (0-based on this handle) takes trace-ring row k % trace_cap, strictly after game k - trace_cap: the row
+// must hold THAT game, finished (and, with trace_hold, released by the host: sc_selfplay_poll).  A long game next to slots
+// that cycle through short ones can be lapped -- writing its rows would corrupt both traces -- and several waiting games
+// can map to the same row (k + cap, k + 2 cap, ...): they start one after the other.  A slot that cannot start parks its
+// ordinal in game_id (ST_PENDING) and retries at every simulation step.
 __device__ inline void try_start_game(SpParams& p, int g, int lane, unsigned long long k) {
     GameCtl& c = p.ctl[g];
     const int ts = (int)(k % (unsigned long long)p.trace_cap);
     const int st = p.thdr[ts].state;
-    const bool busy = st == TR_LIVE || (p.trace_hold && st == TR_DONE);
-    if (busy) {
+    const unsigned long long prev_id = p.thdr[ts].game_id;
+    bool ok;
+    if (k < (unsigned long long)p.trace_cap) ok = st == TR_FREE;   // first use of the row
+    else ok = prev_id == p.first_game_id + k - (unsigned long long)p.trace_cap && (st == TR_FREE || (st == TR_DONE && !p.trace_hold));
+    if (!ok) {
         if (lane == 0) {
             c.status = ST_PENDING;
             c.leaf_kind = LK_NONE;

@@ -299,6 +299,33 @@ def test_trace_ring_never_hands_a_live_row_to_a_new_game(scamd, orc):
     sp.close()
 
 
+def test_trace_ring_orders_several_waiting_games_per_row(scamd, orc):
+    """ring of 6 rows, 3 slots: slot 0 plays a long game (row 0) while slots 1 and 2 burn through ids; game 6 AND game 12
+    both map to row 0 and both wait -- they must take the row one after the other (6 after 0, 12 after 6), not together"""
+    R = 8
+    cfg = dict(rollout_num=R, num_steps=14, cpuct=2.5, temperature=0.0, temperature_switch=2, with_noise=False)
+    sp = scamd.SelfPlay(None, n_slots=3, n_games=15, evaluator="synth", seed=6, outcome_gate=100, trace_capacity=6, trace_hold=True, **cfg)
+    got = {}
+    both_waited = False
+    for it in range(400):
+        for slot in (1, 2):
+            if it < 12 and sp.slot(slot)["status"] == 1 and sp.slot(slot)["game_id"] not in (6, 12):
+                sp.set_position(slot, MATED)             # ids other than 6 and 12 end at once on slots 1 and 2
+        sp.enqueue(R)
+        st = [sp.slot(k) for k in range(3)]
+        both_waited |= sorted(x["game_id"] for x in st if x["status"] == 3) == [6, 12]
+        for g in sp.poll():
+            assert g not in got
+            got[g] = sp.trace(g)
+        if len(got) == 15:
+            break
+    assert both_waited and sorted(got) == list(range(15)) and sp.stats()["error_flags"] == 0
+    for g in (0, 6, 12, 13, 14):
+        ref = orc.selfplay_game(seed=6, game_id=g, outcome_gate=100, **cfg)
+        assert got[g]["steps"] == ref["steps"] and got[g]["outcome"] == ref["outcome"], g
+    sp.close()
+
+
 def test_poll_streams_every_game_once(scamd, orc):
     """sc_selfplay_poll on a bounded ring with many more games than rows: every game is reported exactly once, in time to
     be read, and equals the oracle's game"""
