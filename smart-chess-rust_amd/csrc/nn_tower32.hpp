@@ -241,16 +241,20 @@ __device__ __forceinline__ void conv_mma32(int xoff, const bf16_t* __restrict__ 
 #pragma unroll
         for (int u = 0; u < SPG; u++) {
             const int slot = u % RS;
+#ifndef SC_EXP_NOWLOAD   // experiment builds: the loop without its weight stream / without its image reads
 #pragma unroll
             for (int ct = 0; ct < CT; ct++)
                 bq[(slot + PD) % RS][ct] = (u + PD < SPG) ? wload_p<P>(rsrc, voff, ct, wcur + (u + PD) * SBB)
                                                           : wload_p<P>(rsrc, voff, ct, wnext + (u + PD - SPG) * SBB);
+#endif
+#ifndef SC_EXP_NOLDS
 #pragma unroll
             for (int pt = 0; pt < 2; pt++) {
                 const int v = u + AD;
                 xq[v % AB][pt] = (v < SPG) ? lds_frag_p<P>(pc[v / KPT][pt] + (v % KPT) * KSB)
                                            : lds_frag_p<P>(pn[(v - SPG) / KPT][pt] + ((v - SPG) % KPT) * KSB);
             }
+#endif
 #pragma unroll
             for (int ct = 0; ct < CT; ct++)
 #pragma unroll
