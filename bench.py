@@ -293,13 +293,16 @@ def main():
                "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
         raise SystemExit(subprocess.run(cmd).returncode)
 
+    # under a launcher (torch.distributed.run sets RANK / MASTER_ADDR) the process group is used even with one rank, so the
+    # RCCL path -- rendezvous, barrier, all-reduce of the timing scalars on device tensors -- is the same code at every N
+    use_dist = world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ)
     torch = None
     try:
         import torch  # plumbing only: rendezvous, barrier, max-over-ranks
     except Exception:
-        if world > 1:
+        if use_dist:
             raise
-    if world > 1:
+    if use_dist:
         import torch.distributed as dist
         backend = "gloo" if args.cpu_dry_run else "nccl"
         if backend == "nccl":
@@ -329,7 +332,7 @@ def main():
     # per region: MAX of the time over ranks, SUM of the simulations; the median region (by throughput) is reported
     secs = [r[0] for r in m["regions"]]
     simc = [float(r[1]) for r in m["regions"]]
-    if world > 1:
+    if _dist is not None:
         t = torch.tensor(secs, dtype=torch.float64)
         sv = torch.tensor(simc, dtype=torch.float64)
         if not args.cpu_dry_run:

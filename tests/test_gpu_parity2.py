@@ -422,3 +422,21 @@ def test_encode_positions_rows_are_zero_past_n_legal(scamd):
         assert rc == 0 and (nl == 20).all()
         assert (lm[:, 20:] == 0).all() and (li[:, 20:] == 0).all() and (lm[:, :20] != 0).all()
     eng.close()
+
+
+def test_bench_runs_under_the_launcher_with_rccl(tmp_path):
+    """the driver's multi-GPU form of the bench -- torch.distributed.run, one rank per GPU, backend nccl (= RCCL) -- with the
+    one rank this box has: rendezvous on 127.0.0.1, barrier, all-reduce of the timing scalars on device tensors are the
+    code path of every N (the games themselves never touch a collective)"""
+    import socket
+    import subprocess
+    import sys
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--repeats", "1",
+                        "--no-alt", "--cpu-budget", "0"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["value"] > 1e5 and line["error_flags"] == 0 and line["roofline"]["frac"] > 0.1
