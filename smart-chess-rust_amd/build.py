@@ -39,7 +39,8 @@ def build(force=False, verbose=False):
     hdrs.append(os.path.join(HERE, "..", "include", "sc_engine.h"))
     common = [HIPCC, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
     objs = []
-    for src, extra in (("mcts_kernels.hip", ["-ffp-contract=off"]), ("nn_kernels.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]), ("engine.hip", [])):
+    for src, extra in (("mcts_kernels.hip", ["-ffp-contract=off"]), ("nn_kernels.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]),
+                       ("step_kernels.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]), ("engine.hip", [])):
         s = os.path.join(CSRC, src)
         o = os.path.join(BUILD, src.replace(".hip", ".o"))
         if force or _newer(o, [s] + hdrs):

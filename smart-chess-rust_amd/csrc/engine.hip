@@ -204,6 +204,7 @@ int sc_engine_create(const sc_net_config* cfg, const char* weights_path, int dev
         return fail(m, -2);
     };
     const char* ierr = scl::nn_init();
+    if (!ierr) ierr = scl::step_init();
     if (ierr) {
         sc_engine_destroy(e);
         return fail(std::string("kernel attribute setup failed: ") + ierr);
@@ -516,6 +517,11 @@ struct sc_selfplay {
     // streaming drain (sc_selfplay_poll): per trace-ring row, the game id last reported to the host (+1; 0 = none)
     std::vector<uint64_t> reported;
     std::vector<int> to_release;     // rows handed out by the previous poll (trace_hold)
+#ifdef SC_EXP
+    bool fused = !(getenv("SC_FUSED") && getenv("SC_FUSED")[0] == '0');   // experiment builds: A/B against the two-launch form
+#else
+    bool fused = true;               // search wave + tower in one launch (step_kernels.hip)
+#endif
 };
 
 // complete the last enqueued simulation (expand / backward / ply transition) so that host reads see a
@@ -727,12 +733,39 @@ int sc_selfplay_enqueue_sims(sc_selfplay* sp, int n) {
             q.synth_salt = sp->salt[cur];
             match_tail_params(sp, q, t - 1);
         }
+        const bool timed = p.evaluator == SC_EVAL_NET && sp->timing_stride > 0 && (sp->nn_launches % sp->timing_stride) == 0;
+        if (p.evaluator == SC_EVAL_NET && !timed && sp->fused) {
+            // one launch: the game's search wave (finish the previous simulation, select + encode the next leaf) is wave 0
+            // of its tower workgroup (step_kernels.hip); bit-identical to the two launches below
+            scnn::TowerArgs t{};
+            t.net = e->net;
+            t.n_pos = p.n_slots;
+            t.boards = p.boards;
+            t.meta = p.meta;
+            t.meta_stride = 8;
+            t.legal_idx = p.legal_idx;
+            t.n_legal = p.n_legal;
+            t.prior = p.prior;
+            t.logp = nullptr;
+            t.hval = sp->d_hval;
+            t.dbg = nullptr;
+            t.dbg_stage = -1;
+            scl::step(t, q, 1, s);
+            scnn::Fc1Args f{};
+            f.net = e->net;
+            f.n_pos = p.n_slots;
+            f.ksplit = e->ksplit;
+            f.hval = sp->d_hval;
+            f.vpart = sp->d_vpart;
+            scl::value_fc1(f, s);
+            sp->nn_launches++;
+            continue;
+        }
         // finish the previous simulation (expand/backward/ply transition) and select + encode the next leaf
         scl::mcts(q, 1, 1, s);
         if (p.evaluator != SC_EVAL_NET) {
             scl::synth_eval(q, s);
         } else {
-            bool timed = sp->timing_stride > 0 && (sp->nn_launches % sp->timing_stride) == 0;
             int slot = 0;
             if (timed) {
                 slot = sp->ev_next;

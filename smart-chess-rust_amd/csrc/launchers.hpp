@@ -24,5 +24,8 @@ size_t tower_lds_bytes(int C);
 bool tower_variant_available(int C, bool tower32);   // production builds carry one tower kernel per trunk width
 void tower(const scnn::TowerArgs& a, hipStream_t s);
 void value_fc1(const scnn::Fc1Args& a, hipStream_t s);
+// step_kernels.hip: search wave + tower in one launch (slot g = position g; a.n_pos must equal p.n_slots)
+const char* step_init();
+void step(const scnn::TowerArgs& a, const sc::SpParams& p, int do_expand, hipStream_t s);
 void value_finish(const scnn::VfinArgs& a, hipStream_t s);
 }  // namespace scl

@@ -17,6 +17,7 @@
 //
 // This translation unit is compiled with -ffp-contract=off: the PUCT arithmetic must round
 // exactly like the reference's f32 expression (src/mcts.rs:69-75), which Rust never contracts.
+// SC_NO_KERNELS: only the device functions (step_kernels.hip reuses dev_expand / dev_select inside its own kernel).
 #pragma once
 #include <type_traits>
 #include <hip/hip_runtime.h>
@@ -88,6 +89,7 @@ __device__ __forceinline__ int wave_argmax_last_lane(float u, bool has) {
 // float sum over the wave by DPP (row of 16) + readlanes, in the order of nn_kernels.hpp's wave_sum64 (the fused value
 // tail below and k_value_finish must agree bitwise)
 __device__ __forceinline__ float wave_sum_f_dpp(float v) {
+#pragma clang fp contract(off)   // exact f32 like the reference, in whichever translation unit this is compiled (see wave_sync)
     auto d = [](float x, auto tag) {
         return __builtin_bit_cast(float, dpp_i<decltype(tag)::value>(__builtin_bit_cast(int, x)));
     };
@@ -105,6 +107,16 @@ __device__ inline float wave_sum_f(float v) {
 __device__ inline unsigned long long wave_sum_u64(unsigned long long v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
+}
+
+// Synchronisation inside the search functions (dev_expand, dev_select, finish_game): each game is searched by ONE
+// wavefront -- the whole workgroup of k_mcts, or wave 0 of the tower's workgroup in the fused step kernel (k_step), where a
+// workgroup barrier would wait for waves that never come.  A wave's LDS and vector-memory operations take effect in
+// program order; what is needed between a store by one lane and a load by another is that the compiler keeps that order
+// and the operations have completed: a workgroup-scope fence (s_waitcnt) plus a wave barrier (scheduling only).
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
 }
 
 // Promote a wave-uniform value to SGPRs.  All lanes of a game's wave run the scalar chess logic on identical
@@ -243,9 +255,11 @@ __device__ inline void encode_wave(const Position* s_hist, int n_hist, int lane,
         cell[14 * j + 12] = (f & F_REP2) ? 1 : 0;
         cell[14 * j + 13] = (f & F_REP3) ? 1 : 0;
     }
-    uint4* o16 = reinterpret_cast<uint4*>(out + lane * 112);
+    if (out) {   // (the fused step kernel hands the planes to the network in LDS: no copy to HBM)
+        uint4* o16 = reinterpret_cast<uint4*>(out + lane * 112);
 #pragma unroll
-    for (int k = 0; k < 7; k++) o16[k] = cell16[k];
+        for (int k = 0; k < 7; k++) o16[k] = cell16[k];
+    }
     if (lane == 0) {
         int32_t m[7];
         encode_meta(s_hist[0], m);
@@ -259,6 +273,7 @@ __device__ inline void encode_wave(const Position* s_hist, int n_hist, int lane,
 // get_noise (src/mcts.rs:123-130).  The reference draws from thread_rng; here a counter-based
 // stream keyed by (seed, game, ply, sim, child) -- parity is distributional only.
 __device__ inline float u01_open(uint64_t& st) {
+#pragma clang fp contract(off)   // exact f32 like the reference, in whichever translation unit this is compiled (see wave_sync)
     st = mix64(st);
     return ((float)(st >> 40) + 0.5f) * (1.0f / 16777216.0f);
 }
@@ -268,18 +283,23 @@ __device__ inline float u01_open(uint64_t& st) {
 // routines (10x the instructions): the reference's noise comes from thread_rng, parity is distributional
 // (tests: test_root_noise_is_dirichlet).
 __device__ inline float gamma03(uint64_t st) {
+#pragma clang fp contract(off)   // exact f32 like the reference, in whichever translation unit this is compiled (see wave_sync)
+    // raw hardware transcendentals only (v_log_f32 = log2, v_exp_f32 = 2^x): the library's natural-log / exp wrappers expand
+    // differently with and without FMA contraction, and this function is compiled in two translation units
+    // (mcts_kernels.hip, step_kernels.hip) that must draw the same noise
+    const float LN2 = 0.69314718f;
     const float alpha = 0.3f;
-    const float boost = __expf(__logf(u01_open(st)) * (1.0f / alpha));
+    const float boost = __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(u01_open(st)) * (1.0f / alpha));   // u^(1/alpha)
     const float d = alpha + 1.0f - 1.0f / 3.0f;
     const float c = 0.3390317518f;  // 1 / sqrt(9 d)
     for (int it = 0; it < 64; it++) {
         float a = u01_open(st), b = u01_open(st);
-        float x = __builtin_amdgcn_sqrtf(-2.0f * __logf(a)) * __builtin_amdgcn_cosf(b);   // v_cos_f32 takes revolutions
+        float x = __builtin_amdgcn_sqrtf(-2.0f * LN2 * __builtin_amdgcn_logf(a)) * __builtin_amdgcn_cosf(b);   // v_cos_f32 takes revolutions
         float v = 1.0f + c * x;
         if (v <= 0.0f) continue;
         v = v * v * v;
         float u = u01_open(st);
-        if (__logf(u) < 0.5f * x * x + d - d * v + d * __logf(v)) return boost * d * v;
+        if (LN2 * __builtin_amdgcn_logf(u) < 0.5f * x * x + d - d * v + d * (LN2 * __builtin_amdgcn_logf(v))) return boost * d * v;
     }
     return boost * d;
 }
@@ -292,8 +312,12 @@ constexpr int DEPTH_LDS = 1024;  // path entries tracked in LDS (a deeper path s
         if (p.dbg_cycles && lane == 0) p.dbg_cycles[(size_t)g * 8 + (k)] = clock64(); \
     } while (0)
 
-__device__ __forceinline__ void dev_select(const SpParams& p, int g, int lane, int8_t* s_stage, move_t* s_moves, Position* s_leaf_p,
+// Returns true when the selected leaf needs a network evaluation (planes, legal moves and action indices are then in
+// place).  PLANES_TO_HBM = false: the planes stay in s_stage (fused step kernel).
+template <bool PLANES_TO_HBM = true>
+__device__ __forceinline__ bool dev_select(const SpParams& p, int g, int lane, int8_t* s_stage, move_t* s_moves, Position* s_leaf_p,
                                         uint16_t* s_ps, Position* s_hist, const GameCtl& cs_pre, bool cs_pre_valid) {
+#pragma clang fp contract(off)
     Position& s_leaf = *s_leaf_p;
     SC_STAMP(2);
     GameCtl& c = p.ctl[g];
@@ -314,7 +338,7 @@ __device__ __forceinline__ void dev_select(const SpParams& p, int g, int lane, i
     NodeHdr hdr = uniform(hdr_raw);
     if (cs.status != ST_ACTIVE) {
         if (lane == 0) c.leaf_kind = LK_NONE;
-        return;
+        return false;
     }
     const size_t nb = (size_t)g * p.node_cap;
     const int32_t* N = p.N + nb;
@@ -347,6 +371,7 @@ __device__ __forceinline__ void dev_select(const SpParams& p, int g, int lane, i
         int best_i = 0;
         NodeHdr nxt;
         auto level = [&](auto nrc) {
+#pragma clang fp contract(off)
             constexpr int NRM = decltype(nrc)::value;
             // children statistics AND their headers in one round trip (lane owns children lane, lane+64, ...)
             int cn[NRM];
@@ -485,7 +510,7 @@ __device__ __forceinline__ void dev_select(const SpParams& p, int g, int lane, i
             c.leaf_value = fcl == -2 ? 0.0f : fcl == -3 ? 1.0f : -1.0f;
             c.n_legal = 0;
         }
-        return;
+        return false;
     }
     // position of the leaf (wave-uniform)
     Position pos;
@@ -496,14 +521,14 @@ __device__ __forceinline__ void dev_select(const SpParams& p, int g, int lane, i
         make_move(pos, (move_t)__builtin_amdgcn_readfirstlane((int)MV[node]));  // state.advance (mcts.rs:224)
     }
     if (lane == 0) s_leaf = pos;
-    __syncthreads();  // s_leaf, s_ps visible
+    wave_sync();  // s_leaf, s_ps visible
     DevChain ch{hist, root_ply, tpos, s_ps, &s_leaf, root_ply + depth};
     if (depth > 0) {
         uint8_t rf = (uint8_t)__builtin_amdgcn_readfirstlane((int)rep_flags_wave(ch, root_ply + depth, pos.key, lane));
         pos.flags = (uint8_t)((pos.flags & F_IRREV) | rf);
-        __syncthreads();
+        wave_sync();
         if (lane == 0) s_leaf.flags = pos.flags;
-        __syncthreads();
+        wave_sync();
     }
     SC_STAMP(4);
     // history for the encoder: issued now so the loads overlap move generation
@@ -512,7 +537,7 @@ __device__ __forceinline__ void dev_select(const SpParams& p, int g, int lane, i
     if (lane == 0) tpos[cs.n_exp] = pos;
     int n = 0;
     bool in_check = gen_legal_wave(pos, s_moves, lane, n);   // lane = square (chess_rules_wave.hpp)
-    __syncthreads();
+    wave_sync();
     SC_STAMP(5);
     // --rollout-factor (src/main.rs:175-176): the ply's budget follows from the root's legal-move count, known here at
     // the first simulation of the ply (the only one whose leaf is the root)
@@ -527,7 +552,7 @@ __device__ __forceinline__ void dev_select(const SpParams& p, int g, int lane, i
             c.leaf_value = in_check ? (pos.turn == WHITE ? -1.0f : 1.0f) : 0.0f;
             c.n_legal = 0;
         }
-        return;
+        return false;
     }
     uint16_t* lm = p.legal_mv + (size_t)g * MAXC;
     uint16_t* li = p.legal_idx + (size_t)g * MAXC;
@@ -547,19 +572,21 @@ __device__ __forceinline__ void dev_select(const SpParams& p, int g, int lane, i
         atomicOr(&p.cnt->err, ERR_BAD_MOVE_INDEX);
     }
     const int idx = root_ply + depth;
-    encode_wave(s_hist, idx < 7 ? idx + 1 : 8, lane, s_stage, p.boards + (size_t)g * 7168, p.meta + (size_t)g * 8);
+    encode_wave(s_hist, idx < 7 ? idx + 1 : 8, lane, s_stage, PLANES_TO_HBM ? p.boards + (size_t)g * 7168 : nullptr, p.meta + (size_t)g * 8);
     if (lane == 0) {
         c.leaf_kind = LK_EVAL;
         c.n_legal = n;
         p.n_legal[g] = n;
     }
     SC_STAMP(6);
+    return true;
 }
 
 // ------------------------------------------------------------------ find_max on given values (test aid, sc_debug_find_max)
 // The two argmax forms of the descent on caller-provided PUCT values: out[0] = one-round form (n <= 64, lane = child),
 // out[1] = four-round (value, index) pair form (n <= 256, lane owns children lane, lane+64, ...), exactly as `level`
 // above combines them.  Lets a test place exact ties, -0.0 / +0.0 pairs and maxima in any lane and round.
+#ifndef SC_NO_KERNELS
 __global__ __launch_bounds__(64) void k_debug_find_max(const float* u, int n, int* out) {
     const int lane = threadIdx.x;
     if (n <= 64) {
@@ -584,8 +611,10 @@ __global__ __launch_bounds__(64) void k_debug_find_max(const float* u, int n, in
     const int r4 = wave_argmax_last(best_u, best_i);
     if (lane == 0) out[1] = r4;
 }
+#endif
 
 // ------------------------------------------------------------------ synthetic evaluator (tests)
+#ifndef SC_NO_KERNELS
 __global__ __launch_bounds__(64) void k_synth_eval(SpParams p) {
     const int g = blockIdx.x, lane = threadIdx.x;
     GameCtl& c = p.ctl[g];
@@ -615,6 +644,7 @@ __global__ __launch_bounds__(64) void k_synth_eval(SpParams p) {
         p.value[g] = coarse ? (v < -0.5f ? -0.5f : v >= 0.5f ? 0.5f : 0.0f) : v;
     }
 }
+#endif
 
 // ------------------------------------------------------------------ game (re)start
 // Game ordinal k (0-based on this handle) takes trace-ring row k % trace_cap, strictly after game k - trace_cap: the row
@@ -688,6 +718,7 @@ __device__ inline void start_new_game(SpParams& p, int g, int lane) {
     }
     try_start_game(p, g, lane, k);
 }
+#ifndef SC_NO_KERNELS
 __global__ __launch_bounds__(64) void k_init_slots(SpParams p) {
     const int g = blockIdx.x, lane = threadIdx.x;
     uint4* b = reinterpret_cast<uint4*>(p.boards + (size_t)g * 7168);
@@ -707,6 +738,7 @@ __global__ __launch_bounds__(64) void k_init_slots(SpParams p) {
     }
     try_start_game(p, g, lane, (unsigned long long)g);
 }
+#endif
 
 __device__ inline void finish_game(SpParams& p, int g, int lane, int has_outcome, int term, int winner) {
     GameCtl& c = p.ctl[g];
@@ -722,7 +754,7 @@ __device__ inline void finish_game(SpParams& p, int g, int lane, int has_outcome
         atomicAdd(&p.cnt->games_finished, 1);
         c.status = ST_FINISHED;
     }
-    __syncthreads();
+    wave_sync();
     start_new_game(p, g, lane);
 }
 
@@ -768,6 +800,7 @@ __device__ __forceinline__ void value_tail_issue(const SpParams& p, int g, int l
     t.fc2b = wf[p.vf_fc2b];
 }
 __device__ __forceinline__ float value_tail_finish(const SpParams& p, const ValueTail& t) {
+#pragma clang fp contract(off)   // exact f32 like the reference, in whichever translation unit this is compiled (see wave_sync)
     float m[7];
 #pragma unroll
     for (int k = 0; k < 7; k++) {
@@ -805,6 +838,7 @@ __device__ __forceinline__ float value_tail_finish(const SpParams& p, const Valu
 // cs_out / cs_valid: the control block as this function leaves it, handed to dev_select in registers (a reload would be
 // a load of words stored a few instructions earlier); not valid after a ply transition
 __device__ __forceinline__ void dev_expand(SpParams& p, int g, int lane, Position* s_np_p, GameCtl& cs_out, bool& cs_valid) {
+#pragma clang fp contract(off)
     Position& s_np = *s_np_p;
     GameCtl& c = p.ctl[g];
     // First round trip: EVERYTHING whose address depends on the game slot only -- the control block (one 64-byte
@@ -904,7 +938,7 @@ __device__ __forceinline__ void dev_expand(SpParams& p, int g, int lane, Positio
         N[nd] += 1;
         W[nd] += value;
     }
-    __syncthreads();
+    wave_sync();
     int sim = cs.sim + 1;
     if (lane == 0) {
         c.n_nodes = n_nodes;
@@ -930,8 +964,7 @@ __device__ __forceinline__ void dev_expand(SpParams& p, int g, int lane, Positio
     cs_valid = false;
 
     // ---------------- end of this ply's search (main.rs:198-233)
-    __threadfence_block();
-    __syncthreads();
+    wave_sync();
     const int ply = cs.ply;
     const NodeHdr h0 = H[0];
     const int nc = h0.nc, fc = h0.fc;
@@ -1015,19 +1048,18 @@ __device__ __forceinline__ void dev_expand(SpParams& p, int g, int lane, Positio
     Position np = uniform(hist[ply]);
     make_move(np, (move_t)uniform((int)mv));
     if (lane == 0) s_np = np;
-    __syncthreads();
+    wave_sync();
     {
         DevChain ch{hist, ply, tpos, nullptr, &s_np, ply + 1};
         uint8_t rf = rep_flags_wave(ch, ply + 1, np.key, lane);
         np.flags = (uint8_t)((np.flags & F_IRREV) | rf);
     }
-    __syncthreads();
+    wave_sync();
     if (lane == 0) {
         hist[ply + 1] = np;
         atomicAdd(&p.cnt->plies_done, 1ULL);
     }
-    __threadfence_block();
-    __syncthreads();
+    wave_sync();
     const int new_ply = ply + 1;
     if (lane == 0) c.ply = new_ply;
     const int i_step = ply - cs.start_ply;  // the reference's loop index i
@@ -1036,13 +1068,13 @@ __device__ __forceinline__ void dev_expand(SpParams& p, int g, int lane, Positio
         int winner = -1;
         int term = outcome_claim_draw(hc, new_ply, &winner);
         if (term != T_NONE) {
-            __syncthreads();
+            wave_sync();
             finish_game(p, g, lane, 1, term, winner);
             return;
         }
     }
     if (i_step + 1 >= p.num_steps || new_ply + 1 >= p.hist_cap) {  // loop ends: outcome stays null
-        __syncthreads();
+        wave_sync();
         finish_game(p, g, lane, 0, 0, -1);
         return;
     }
@@ -1063,6 +1095,7 @@ __device__ __forceinline__ void dev_expand(SpParams& p, int g, int lane, Positio
 
 // One launch per simulation step: finish the previous simulation of every game (value head tail, expand,
 // backward, and at the end of a ply mcts::step + trace + outcome), then select the next leaf and encode it.
+#ifndef SC_NO_KERNELS
 __global__ __launch_bounds__(64) void k_mcts(SpParams p, int do_expand, int do_select) {
     const int g = blockIdx.x, lane = threadIdx.x;
     __shared__ __attribute__((aligned(16))) int8_t s_stage[7168];
@@ -1083,8 +1116,10 @@ __global__ __launch_bounds__(64) void k_mcts(SpParams p, int do_expand, int do_s
     SC_STAMP(1);
     if (do_select) dev_select(p, g, lane, s_stage, s_moves, &s_pos, s_ps, s_hist, cs_pre, cs_pre_valid);
 }
+#endif
 
 // ------------------------------------------------------------------ sc_selfplay_set_position
+#ifndef SC_NO_KERNELS
 __global__ __launch_bounds__(64) void k_set_position(SpParams p, int g, const uint16_t* moves, int n_moves) {
     const int lane = threadIdx.x;
     GameCtl& c = p.ctl[g];
@@ -1124,6 +1159,7 @@ __global__ __launch_bounds__(64) void k_set_position(SpParams p, int g, const ui
         c.status = ST_ACTIVE;
     }
 }
+#endif
 
 // ------------------------------------------------------------------ sc_encode_positions
 // One wave per position: replay the move list from the start position (validating every move
@@ -1131,6 +1167,7 @@ __global__ __launch_bounds__(64) void k_set_position(SpParams p, int g, const ui
 // and outcome(claim_draw=True).  hist scratch: [n][hist_cap] Positions.
 // move_len (optional): position g replays moves[move_off[g] .. move_off[g] + move_len[g]) -- prefixes of one game
 // share their start (used by the training-tensor encoder: one position per ply).
+#ifndef SC_NO_KERNELS
 __global__ __launch_bounds__(64) void k_encode_positions(int n_pos, const uint16_t* moves, const uint32_t* move_off,
                                                          const uint32_t* move_len, Position* hist_all, int hist_cap, int8_t* boards, int32_t* meta,
                                                          uint16_t* legal_mv, uint16_t* legal_idx, int32_t* n_legal,
@@ -1209,6 +1246,7 @@ __global__ __launch_bounds__(64) void k_encode_positions(int n_pos, const uint16
         }
     }
 }
+#endif
 
 // ------------------------------------------------------------------ training tensors
 // Per ply of a recorded game: libsmartchess.chess_encode_steps (reference src/lib.rs:46-128) on top of
@@ -1220,6 +1258,7 @@ __global__ __launch_bounds__(64) void k_encode_positions(int n_pos, const uint16
 //     view, lib.rs:80-98 + chess.rs:827-842 -- asserted on the oracle's literal restatement); meta becomes that of
 //     Board::rotate(): [!turn, fullmove + (turn==White), K(opp), Q(opp), K(mover), Q(mover), halfmove].
 // One wavefront per ply; HBM-bound writer (18.7 KB of dist per ply).
+#ifndef SC_NO_KERNELS
 __global__ __launch_bounds__(64) void k_steps_dist(int n, const uint16_t* legal_mv, const int32_t* n_legal, const uint16_t* next_mv,
                                                    const uint16_t* child_mv, const uint32_t* child_n, const uint32_t* child_off,
                                                    int apply_mirror, int32_t* meta, float* dist, int32_t* flags) {
@@ -1275,5 +1314,6 @@ __global__ __launch_bounds__(64) void k_steps_dist(int n, const uint16_t* legal_
         }
     }
 }
+#endif
 
 }  // namespace sc

@@ -125,6 +125,7 @@ __device__ __forceinline__ void vec_mma(const bf16_t* x, const VecW<K, NTW>& v, 
 template <int NTW>
 __device__ inline int chan0(int wave, int lane) { return wave * (16 * NTW) + (lane & 15) * NTW; }
 
+#ifndef SC_NO_KERNELS
 // --------------------------------------------------------------------------------------------
 // value_head.ffn.0 (Linear 16391->128) over the whole batch: out[b][j] = sum_k hval[b][k] W[k][j].
 // grid = (ceil(n/64), KSPLIT); block 256 = 4 waves, wave w owns column tiles 2w, 2w+1.
@@ -218,5 +219,7 @@ __global__ __launch_bounds__(64) void k_value_finish(VfinArgs A) {
         A.value[pos] = v * (float)(A.meta[(size_t)pos * A.meta_stride] * 2 - 1);
     }
 }
+
+#endif  // SC_NO_KERNELS
 
 }  // namespace scnn

@@ -472,11 +472,11 @@ constexpr int tower32_lds_bytes(int C) {
 
 // P: precision policy of the convs; AB: image-fragment buffers of the trunk convs; HRS / H2RS: ring slots of the head convs
 // (their rings hold a wave's whole weight stream).
+// tower_body: the network for position `pos`, run by the 256 threads of one workgroup.  planes_lds: the position's input
+// planes int8[64][112] in LDS (the fused step kernel, step_kernels.hip: the search wave has just encoded them there), or
+// nullptr: read them from A.boards.
 template <class P, int C, int RS, int TPI, int AB = SC_T32_AB>
-#ifndef SC_T32_OCC
-#define SC_T32_OCC 1
-#endif
-__global__ __launch_bounds__(256, SC_T32_OCC) void k_tower32(TowerArgs A) {
+__device__ __forceinline__ void tower_body(const TowerArgs& A, const int pos, const int8_t* planes_lds) {
     typedef typename P::frag frag;
     constexpr int CT = C / 128;        // 32-channel tiles per wave in the trunk
     constexpr int TILES = C / 32;
@@ -499,8 +499,6 @@ __global__ __launch_bounds__(256, SC_T32_OCC) void k_tower32(TowerArgs A) {
     static_assert(4864 * 4 <= XA_BYTES, "policy logits (and the softmax pass that reads 19 x 256 of them) must fit in the image area");
     static_assert(XA_BYTES % 16 == 0 && RS_BYTES % 16 == 0, "LDS regions must stay 16-byte aligned");
 
-    const int pos = blockIdx.x;
-    if (pos >= A.n_pos) return;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i32 = lane & 31, h = lane >> 5;
@@ -528,7 +526,11 @@ __global__ __launch_bounds__(256, SC_T32_OCC) void k_tower32(TowerArgs A) {
     // LDS like the per-block parameters).  Their trip from HBM / L2 overlaps the zero fill instead of following it.
     const int p_in = tid >> 2, q_in = tid & 3;
     uint32_t win[7];
-    {
+    if (planes_lds) {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(planes_lds + p_in * 112 + q_in * 28);
+#pragma unroll
+        for (int k = 0; k < 7; k++) win[k] = src[k];
+    } else {
         const uint32_t* src = reinterpret_cast<const uint32_t*>(A.boards + (size_t)pos * 7168 + p_in * 112 + q_in * 28);
 #pragma unroll
         for (int k = 0; k < 7; k++) win[k] = src[k];
@@ -943,6 +945,15 @@ __global__ __launch_bounds__(256, SC_T32_OCC) void k_tower32(TowerArgs A) {
     if (stampv.on)
         for (int k = 0; k < 40; k++) A.dbg[(size_t)pos * 64 * C + wave * 40 + k] = (float)stampv.t[k];
 #endif
+}
+
+#ifndef SC_T32_OCC
+#define SC_T32_OCC 1
+#endif
+template <class P, int C, int RS, int TPI, int AB = SC_T32_AB>
+__global__ __launch_bounds__(256, SC_T32_OCC) void k_tower32(TowerArgs A) {
+    if ((int)blockIdx.x >= A.n_pos) return;
+    tower_body<P, C, RS, TPI, AB>(A, (int)blockIdx.x, nullptr);
 }
 
 }  // namespace scnn

@@ -440,3 +440,26 @@ def test_bench_runs_under_the_launcher_with_rccl(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 1 and line["value"] > 1e5 and line["error_flags"] == 0 and line["roofline"]["frac"] > 0.1
+
+
+@pytest.mark.parametrize("C,precision", [(128, "bf16"), (256, "bf16"), (128, "fp8")])
+def test_fused_step_kernel_equals_the_two_launch_form(scamd, C, precision):
+    """the fused simulation step (search wave = wave 0 of the tower workgroup, planes handed over in LDS) plays bit-identical
+    games to k_mcts + k_tower32 as separate launches (which a handle uses while every launch is timed): moves, visit
+    counts, value sums and uct words of every ply, with root noise, temperature sampling and slot recycling"""
+    eng = scamd.Engine(3, C, seed=4, precision=precision)
+    cfg = dict(n_slots=24, n_games=40, rollout_num=20, num_steps=9, cpuct=2.5, temperature=0.5, temperature_switch=3, with_noise=True, seed=12,
+               outcome_gate=0)
+    a = scamd.SelfPlay(eng, **cfg)
+    a.run()
+    b = scamd.SelfPlay(eng, **cfg)
+    b.enable_timing(1)                       # every tower launch bracketed by events: the two-launch form
+    b.run()
+    assert b.timing(reset=False)["tower_launches"] > 100
+    for g in range(40):
+        ta, tb = a.trace(g), b.trace(g)
+        assert ta is not None and ta == tb, g
+    assert a.stats() == b.stats() and a.stats()["error_flags"] == 0 and a.stats()["games_finished"] == 40
+    for h in (a, b):
+        h.close()
+    eng.close()
