@@ -50,6 +50,7 @@ struct sc_engine {
     scnn::NetDev net{};
     uint16_t* d_wb = nullptr;
     float* d_wf = nullptr;
+    int n_cu = 256;    // compute units of the device
     int ksplit = 64;   // split-K of value_head.ffn.0 (the search kernel's fused tail sums 32 or 64 partials)
     // scratch, grown on demand
     int cap = 0;
@@ -215,6 +216,10 @@ int sc_engine_create(const sc_net_config* cfg, const char* weights_path, int dev
     if ((he = dalloc(&e->d_wf, pk.wf.size())) != hipSuccess) return bail(he, "hipMalloc(parameters)");
     if ((he = hipMemcpy(e->d_wb, pk.wb.data(), pk.wb.size() * 2, hipMemcpyHostToDevice)) != hipSuccess) return bail(he, "hipMemcpy(weights)");
     if ((he = hipMemcpy(e->d_wf, pk.wf.data(), pk.wf.size() * 4, hipMemcpyHostToDevice)) != hipSuccess) return bail(he, "hipMemcpy(parameters)");
+    {
+        int ncu = 0;
+        if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device_id) == hipSuccess && ncu > 0) e->n_cu = ncu;
+    }
     static_cast<scnn::NetLayout&>(e->net) = pk.lay;
     e->net.wb = e->d_wb;
     e->net.wf = e->d_wf;
@@ -517,11 +522,12 @@ struct sc_selfplay {
     // streaming drain (sc_selfplay_poll): per trace-ring row, the game id last reported to the host (+1; 0 = none)
     std::vector<uint64_t> reported;
     std::vector<int> to_release;     // rows handed out by the previous poll (trace_hold)
-#ifdef SC_EXP
-    bool fused = !(getenv("SC_FUSED") && getenv("SC_FUSED")[0] == '0');   // experiment builds: A/B against the two-launch form
-#else
-    bool fused = true;               // search wave + tower in one launch (step_kernels.hip)
-#endif
+    // search wave + tower in one launch (step_kernels.hip).  Chosen at creation: only with at most one game per compute
+    // unit and a single group -- with more games than CUs the separate search launch runs all of them at once while the
+    // fused workgroups (83 KB of LDS: one per CU) would take turns, and with several interleaved groups one group's search
+    // launch is what hides under another group's tower (measured: 512 games 3.48 M vs 3.02 M simulations/s at fp8, two
+    // groups of 256 2.65 M vs 2.38 M at bf16, in favour of the separate launches)
+    bool fused = false;
 };
 
 // complete the last enqueued simulation (expand / backward / ply transition) so that host reads see a
@@ -674,6 +680,10 @@ int sc_selfplay_create(sc_engine* e, int device_id, const sc_selfplay_config* cf
         p.vf_fc2b = (uint32_t)e->net.f_fc2b;
     }
     sp->reported.assign((size_t)p.trace_cap, 0);
+    sp->fused = e && cfg->evaluator == SC_EVAL_NET && cfg->n_slots <= e->n_cu && !cfg->own_stream;
+#ifdef SC_EXP
+    if (getenv("SC_FUSED")) sp->fused = getenv("SC_FUSED")[0] != '0';   // experiment builds: A/B
+#endif
     // the zero-fills above ran on the NULL stream, which does not order against the (non-blocking) launch
     // stream: make them complete before the first kernel touches the buffers
     hipError_t he = hipDeviceSynchronize();
