@@ -21,6 +21,8 @@
 //     {2t+1, 2t+5} in group B; with a pixel stride of an odd multiple of 16 B the 16 haloed addresses of every
 //     lane group fall on 16 distinct 16-byte bank slots for every 3x3 tap.
 #pragma once
+#include <type_traits>
+
 #include "nn_kernels.hpp"
 
 namespace scnn {
@@ -473,10 +475,17 @@ constexpr int tower32_lds_bytes(int C) {
 // P: precision policy of the convs; AB: image-fragment buffers of the trunk convs; HRS / H2RS: ring slots of the head convs
 // (their rings hold a wave's whole weight stream).
 // tower_body: the network for position `pos`, run by the 256 threads of one workgroup.  planes_lds: the position's input
-// planes int8[64][112] in LDS (the fused step kernel, step_kernels.hip: the search wave has just encoded them there), or
-// nullptr: read them from A.boards.
-template <class P, int C, int RS, int TPI, int AB = SC_T32_AB>
-__device__ __forceinline__ void tower_body(const TowerArgs& A, const int pos, const int8_t* planes_lds) {
+// planes int8[64][112] in LDS, or nullptr: read them from A.boards.
+// Pre (fused step kernel, step_kernels.hip): work that wave 0 does BEFORE the network -- the game's tree search, which ends
+// by encoding the planes into planes_lds and says whether the leaf needs the network at all.  It is called after every
+// wave has requested its first weights and the stem parameters, and while waves 1..3 zero the image: the tower's cold
+// prologue runs under the search instead of after it.
+struct NoPre {
+    __device__ __forceinline__ bool operator()() const { return true; }
+};
+template <class P, int C, int RS, int TPI, int AB = SC_T32_AB, class Pre = NoPre>
+__device__ __forceinline__ void tower_body(const TowerArgs& A, const int pos, const int8_t* planes_lds, Pre pre = Pre()) {
+    constexpr bool FUSED = !std::is_same<Pre, NoPre>::value;
     typedef typename P::frag frag;
     constexpr int CT = C / 128;        // 32-channel tiles per wave in the trunk
     constexpr int TILES = C / 32;
@@ -526,11 +535,7 @@ __device__ __forceinline__ void tower_body(const TowerArgs& A, const int pos, co
     // LDS like the per-block parameters).  Their trip from HBM / L2 overlaps the zero fill instead of following it.
     const int p_in = tid >> 2, q_in = tid & 3;
     uint32_t win[7];
-    if (planes_lds) {
-        const uint32_t* src = reinterpret_cast<const uint32_t*>(planes_lds + p_in * 112 + q_in * 28);
-#pragma unroll
-        for (int k = 0; k < 7; k++) win[k] = src[k];
-    } else {
+    if (!FUSED && !planes_lds) {
         const uint32_t* src = reinterpret_cast<const uint32_t*>(A.boards + (size_t)pos * 7168 + p_in * 112 + q_in * 28);
 #pragma unroll
         for (int k = 0; k < 7; k++) win[k] = src[k];
@@ -542,11 +547,27 @@ __device__ __forceinline__ void tower_body(const TowerArgs& A, const int pos, co
     ring_fill<P, CT, TILES, RS>(ring, net.wb + net.o_stem, wave, lane);   // the stem's first weights too
     __builtin_amdgcn_sched_barrier(0);
     // ---- zero the image (halo stays zero for the whole kernel), then write the 112 input planes
-    {
+    if constexpr (FUSED) {
+        __shared__ int s_go;
+        if (wave == 0) {
+            const bool go = pre();
+            if (lane == 0) s_go = go ? 1 : 0;
+        } else {
+            uint4* z = reinterpret_cast<uint4*>(smem);
+            for (int k = tid - 64; k < 100 * PSB / 16; k += 192) z[k] = make_uint4(0, 0, 0, 0);
+        }
+        __syncthreads();   // image zeroed; planes in planes_lds, legal moves / indices stored (the barrier waits for wave 0's stores)
+        if (!s_go) return; // terminal leaf or idle slot: no network evaluation this step
+    } else {
         uint4* z = reinterpret_cast<uint4*>(smem);
         for (int k = tid; k < 100 * PSB / 16; k += 256) z[k] = make_uint4(0, 0, 0, 0);
+        __syncthreads();
     }
-    __syncthreads();
+    if (FUSED || planes_lds) {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(planes_lds + p_in * 112 + q_in * 28);
+#pragma unroll
+        for (int k = 0; k < 7; k++) win[k] = src[k];
+    }
     {
         uint32_t* dst = reinterpret_cast<uint32_t*>(smem + hidx(p_in) * PSB + q_in * 28 * EB);   // 28-plane groups: 4-byte aligned
 #pragma unroll

@@ -3,8 +3,8 @@
 // k_mcts (one wavefront per game) and the network tower (one 4-wave workgroup per position) work on the SAME game on the
 // SAME compute unit back to back: here the game's search wave is wave 0 of its tower workgroup.  It finishes the previous
 // simulation (value-head tail, expand, backup -- dev_expand), selects the next leaf and encodes its planes into LDS
-// (dev_select); the other three waves meanwhile park at the workgroup barrier; then all four run the tower on the planes in
-// LDS.  Saved per simulation step: one launch ramp, the tower's cold prologue behind a kernel boundary, and the 7 KB
+// (dev_select) -- inside the tower's prologue: every wave has already requested its first weights and the stem parameters,
+// and the other three waves zero the LDS image meanwhile; then all four run the tower on the planes in LDS.  Saved per simulation step: one launch ramp, the tower's cold prologue behind a kernel boundary, and the 7 KB
 // round trip of the planes through HBM.  A game whose leaf needs no network (terminal position, idle slot) skips the tower.
 // Bit-identical to k_mcts + k_tower32 (same device functions): tests/test_gpu_parity*.py run through this path; the
 // unfused pair remains for the synthetic evaluators, the final flush and the timed samples of the bench.
@@ -30,22 +30,20 @@ __global__ __launch_bounds__(256, 1) void k_step(scnn::TowerArgs A, sc::SpParams
     __shared__ sc::Position s_pos;
     __shared__ sc::Position s_hist[8];
     __shared__ uint16_t s_ps[sc::DEPTH_LDS];
-    __shared__ int s_go;
     const int g = blockIdx.x;
-    if (threadIdx.x < 64) {
-        const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    // wave 0: the game's search; it runs inside the tower's prologue (tower_body, Pre), after every wave has requested its
+    // first weights and while waves 1..3 zero the image
+    auto search = [&]() -> bool {
         sc::GameCtl cs_pre{};
         bool cs_pre_valid = false;
         if (do_expand) {
             sc::dev_expand(p, g, lane, &s_pos, cs_pre, cs_pre_valid);
             __builtin_amdgcn_wave_barrier();
         }
-        const bool go = sc::dev_select<false>(p, g, lane, s_stage, s_moves, &s_pos, s_ps, s_hist, cs_pre, cs_pre_valid);
-        if (lane == 0) s_go = go ? 1 : 0;
-    }
-    __syncthreads();   // planes in s_stage, legal moves / indices / n_legal stored (the barrier waits for the wave's stores)
-    if (!s_go) return;
-    scnn::tower_body<P, C, RS, TPI, AB>(A, g, s_stage);
+        return sc::dev_select<false>(p, g, lane, s_stage, s_moves, &s_pos, s_ps, s_hist, cs_pre, cs_pre_valid);
+    };
+    scnn::tower_body<P, C, RS, TPI, AB>(A, g, s_stage, search);
 }
 
 }  // namespace scstep
