@@ -312,11 +312,47 @@ constexpr int DEPTH_LDS = 1024;  // path entries tracked in LDS (a deeper path s
         if (p.dbg_cycles && lane == 0) p.dbg_cycles[(size_t)g * 8 + (k)] = clock64(); \
     } while (0)
 
+// Hand-off to a helper wavefront (fused step kernel): once the leaf position and its repetition flags stand, the plane
+// encoding (history loads + 7 KB of LDS writes) is independent of move generation; wave 1 of the workgroup, idle during
+// the search, does it while this wave generates the moves.  An LDS mailbox: the searching wave writes idx / root_ply,
+// then state (1 = encode, 2 = nothing to do); the helper polls state.
+struct HelperBox {
+    int state, idx, root_ply, pad;
+};
+__device__ __forceinline__ void helper_post(HelperBox* box, int lane, int state, int idx, int root_ply) {
+    if (!box) return;
+    if (lane == 0) {
+        box->idx = idx;
+        box->root_ply = root_ply;
+    }
+    wave_sync();   // the payload (and s_leaf / s_ps before it) has landed in LDS before the state word is written
+    if (lane == 0) *reinterpret_cast<volatile int*>(&box->state) = state;
+}
+// the helper wave: waits for the mailbox, encodes the planes of the leaf into `stage` (and its meta row)
+__device__ __forceinline__ void dev_encode_helper(const SpParams& p, int g, int lane, HelperBox* box, int8_t* s_stage, Position* s_leaf_p,
+                                                  uint16_t* s_ps, Position* s_hist) {
+    int st = 0;
+    for (int spin = 0; spin < (1 << 22) && st == 0; spin++) {   // bounded: a wave never hangs on a missing post
+        st = *reinterpret_cast<volatile int*>(&box->state);
+        if (st == 0) __builtin_amdgcn_s_sleep(2);
+    }
+    st = __builtin_amdgcn_readfirstlane(st);
+    if (st != 1) return;
+    wave_sync();
+    const int idx = __builtin_amdgcn_readfirstlane(box->idx), root_ply = __builtin_amdgcn_readfirstlane(box->root_ply);
+    DevChain ch{p.hist + (size_t)g * p.hist_cap, root_ply, p.tpos + (size_t)g * p.tpos_cap, s_ps, s_leaf_p, idx};
+    stage_history(ch, idx, lane, s_hist);
+    wave_sync();
+    encode_wave(s_hist, idx < 7 ? idx + 1 : 8, lane, s_stage, nullptr, p.meta + (size_t)g * 8);
+}
+
 // Returns true when the selected leaf needs a network evaluation (planes, legal moves and action indices are then in
-// place).  PLANES_TO_HBM = false: the planes stay in s_stage (fused step kernel).
+// place).  PLANES_TO_HBM = false: the planes stay in s_stage (fused step kernel).  box != nullptr: the planes are encoded
+// by the helper wave (above) instead of this one.
 template <bool PLANES_TO_HBM = true>
 __device__ __forceinline__ bool dev_select(const SpParams& p, int g, int lane, int8_t* s_stage, move_t* s_moves, Position* s_leaf_p,
-                                        uint16_t* s_ps, Position* s_hist, const GameCtl& cs_pre, bool cs_pre_valid) {
+                                        uint16_t* s_ps, Position* s_hist, const GameCtl& cs_pre, bool cs_pre_valid,
+                                        HelperBox* box = nullptr) {
 #pragma clang fp contract(off)
     Position& s_leaf = *s_leaf_p;
     SC_STAMP(2);
@@ -338,6 +374,7 @@ __device__ __forceinline__ bool dev_select(const SpParams& p, int g, int lane, i
     NodeHdr hdr = uniform(hdr_raw);
     if (cs.status != ST_ACTIVE) {
         if (lane == 0) c.leaf_kind = LK_NONE;
+        helper_post(box, lane, 2, 0, 0);
         return false;
     }
     const size_t nb = (size_t)g * p.node_cap;
@@ -510,6 +547,7 @@ __device__ __forceinline__ bool dev_select(const SpParams& p, int g, int lane, i
             c.leaf_value = fcl == -2 ? 0.0f : fcl == -3 ? 1.0f : -1.0f;
             c.n_legal = 0;
         }
+        helper_post(box, lane, 2, 0, 0);
         return false;
     }
     // position of the leaf (wave-uniform)
@@ -531,8 +569,10 @@ __device__ __forceinline__ bool dev_select(const SpParams& p, int g, int lane, i
         wave_sync();
     }
     SC_STAMP(4);
-    // history for the encoder: issued now so the loads overlap move generation
-    stage_history(ch, root_ply + depth, lane, s_hist);
+    // history for the encoder: issued now so the loads overlap move generation -- or the whole encoding handed to the
+    // helper wave (a terminal leaf wastes its work: nothing reads the planes then)
+    if (box) helper_post(box, lane, 1, root_ply + depth, root_ply);
+    else stage_history(ch, root_ply + depth, lane, s_hist);
     // scratch slot for the expansion (claimed in dev_expand if the leaf is not terminal)
     if (lane == 0) tpos[cs.n_exp] = pos;
     int n = 0;
@@ -572,7 +612,7 @@ __device__ __forceinline__ bool dev_select(const SpParams& p, int g, int lane, i
         atomicOr(&p.cnt->err, ERR_BAD_MOVE_INDEX);
     }
     const int idx = root_ply + depth;
-    encode_wave(s_hist, idx < 7 ? idx + 1 : 8, lane, s_stage, PLANES_TO_HBM ? p.boards + (size_t)g * 7168 : nullptr, p.meta + (size_t)g * 8);
+    if (!box) encode_wave(s_hist, idx < 7 ? idx + 1 : 8, lane, s_stage, PLANES_TO_HBM ? p.boards + (size_t)g * 7168 : nullptr, p.meta + (size_t)g * 8);
     if (lane == 0) {
         c.leaf_kind = LK_EVAL;
         c.n_legal = n;

@@ -476,12 +476,12 @@ constexpr int tower32_lds_bytes(int C) {
 // (their rings hold a wave's whole weight stream).
 // tower_body: the network for position `pos`, run by the 256 threads of one workgroup.  planes_lds: the position's input
 // planes int8[64][112] in LDS, or nullptr: read them from A.boards.
-// Pre (fused step kernel, step_kernels.hip): work that wave 0 does BEFORE the network -- the game's tree search, which ends
-// by encoding the planes into planes_lds and says whether the leaf needs the network at all.  It is called after every
-// wave has requested its first weights and the stem parameters, and while waves 1..3 zero the image: the tower's cold
-// prologue runs under the search instead of after it.
+// Pre (fused step kernel, step_kernels.hip): work that waves 0 and 1 do BEFORE the network -- pre(0) is the game's tree
+// search and says whether the leaf needs the network at all, pre(1) its helper; between them they leave the planes in
+// planes_lds.  Called after every wave has requested its first weights and the stem parameters, and while waves 2 and 3
+// zero the image: the tower's cold prologue runs under the search instead of after it.
 struct NoPre {
-    __device__ __forceinline__ bool operator()() const { return true; }
+    __device__ __forceinline__ bool operator()(int) const { return true; }
 };
 template <class P, int C, int RS, int TPI, int AB = SC_T32_AB, class Pre = NoPre>
 __device__ __forceinline__ void tower_body(const TowerArgs& A, const int pos, const int8_t* planes_lds, Pre pre = Pre()) {
@@ -549,12 +549,12 @@ __device__ __forceinline__ void tower_body(const TowerArgs& A, const int pos, co
     // ---- zero the image (halo stays zero for the whole kernel), then write the 112 input planes
     if constexpr (FUSED) {
         __shared__ int s_go;
-        if (wave == 0) {
-            const bool go = pre();
-            if (lane == 0) s_go = go ? 1 : 0;
+        if (wave <= 1) {   // wave 0: the search; wave 1: its helper (plane encoding)
+            const bool go = pre(wave);
+            if (wave == 0 && lane == 0) s_go = go ? 1 : 0;
         } else {
             uint4* z = reinterpret_cast<uint4*>(smem);
-            for (int k = tid - 64; k < 100 * PSB / 16; k += 192) z[k] = make_uint4(0, 0, 0, 0);
+            for (int k = tid - 128; k < 100 * PSB / 16; k += 128) z[k] = make_uint4(0, 0, 0, 0);
         }
         __syncthreads();   // image zeroed; planes in planes_lds, legal moves / indices stored (the barrier waits for wave 0's stores)
         if (!s_go) return; // terminal leaf or idle slot: no network evaluation this step

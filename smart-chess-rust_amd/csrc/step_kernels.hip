@@ -30,18 +30,25 @@ __global__ __launch_bounds__(256, 1) void k_step(scnn::TowerArgs A, sc::SpParams
     __shared__ sc::Position s_pos;
     __shared__ sc::Position s_hist[8];
     __shared__ uint16_t s_ps[sc::DEPTH_LDS];
+    __shared__ sc::HelperBox s_box;
     const int g = blockIdx.x;
     const int lane = threadIdx.x & 63;
-    // wave 0: the game's search; it runs inside the tower's prologue (tower_body, Pre), after every wave has requested its
-    // first weights and while waves 1..3 zero the image
-    auto search = [&]() -> bool {
+    // wave 0: the game's search, wave 1: its helper (encodes the leaf's planes while wave 0 generates the moves); both run
+    // inside the tower's prologue (tower_body, Pre), after every wave has requested its first weights
+    if (threadIdx.x == 0) s_box.state = 0;   // LDS starts with whatever the previous workgroup left: clear the mailbox ...
+    __syncthreads();                         // ... before wave 1 can poll it or wave 0 post to it
+    auto search = [&](int wave) -> bool {
+        if (wave == 1) {
+            sc::dev_encode_helper(p, g, lane, &s_box, s_stage, &s_pos, s_ps, s_hist);
+            return true;
+        }
         sc::GameCtl cs_pre{};
         bool cs_pre_valid = false;
         if (do_expand) {
             sc::dev_expand(p, g, lane, &s_pos, cs_pre, cs_pre_valid);
             __builtin_amdgcn_wave_barrier();
         }
-        return sc::dev_select<false>(p, g, lane, s_stage, s_moves, &s_pos, s_ps, s_hist, cs_pre, cs_pre_valid);
+        return sc::dev_select<false>(p, g, lane, s_stage, s_moves, &s_pos, s_ps, s_hist, cs_pre, cs_pre_valid, &s_box);
     };
     scnn::tower_body<P, C, RS, TPI, AB>(A, g, s_stage, search);
 }
