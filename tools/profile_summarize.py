@@ -51,7 +51,7 @@ def main(tag, ch, key=None):
         fk, wk = fetch.get(k, (0, 0)), write.get(k, (0, 0))
         by = fk[0] * 1024 * 2 + wk[0] * 1024
         rows.append((k, fk[1], fk[0], wk[0], by))
-        if "k_tower" in k:
+        if (key or "k_tower").split("<")[0] in k:   # the kernel the key names (k_tower32 by default, k_step for the fused pipeline)
             traffic[key or f"k_tower32<{ch}>"] = round(by)
     with open(os.path.join(dst, f"{tag}_c{ch}_pmc_hbm.csv"), "w") as f:
         f.write("kernel,launches,avg_FETCH_SIZE_KiB,avg_WRITE_SIZE_KiB,hbm_bytes_per_launch(2*FETCH+WRITE)*1024\n")
