@@ -971,15 +971,24 @@ int sc_selfplay_get_trace(sc_selfplay* sp, int game, sc_trace_info* info, uint16
         }
         child_off[ns] = off;
     }
-    if (child_move || child_n || child_q || child_uct) {
+    if ((child_move || child_n || child_q || child_uct) && ns) {
+        // one copy per array for the whole game (rows of 224 entries per ply), compacted on the host: a copy per ply and
+        // array cost more than the games themselves when many short games stream out
+        const size_t rows = (size_t)ns * 224, src = base * 224;
+        std::vector<uint16_t> mv(child_move ? rows : 0);
+        std::vector<int32_t> cn(child_n ? rows : 0);
+        std::vector<float> cq(child_q ? rows : 0), cu(child_uct ? rows : 0);
+        if (child_move) HIPOK(hipMemcpy(mv.data(), p.t_cmove + src, rows * 2, hipMemcpyDeviceToHost));
+        if (child_n) HIPOK(hipMemcpy(cn.data(), p.t_cn + src, rows * 4, hipMemcpyDeviceToHost));
+        if (child_q) HIPOK(hipMemcpy(cq.data(), p.t_cq + src, rows * 4, hipMemcpyDeviceToHost));
+        if (child_uct) HIPOK(hipMemcpy(cu.data(), p.t_cu + src, rows * 4, hipMemcpyDeviceToHost));
         int off = 0;
         for (int i = 0; i < ns; i++) {
-            size_t src = (base + (size_t)i) * 224;
-            size_t n = (size_t)nch[(size_t)i];
-            if (child_move) HIPOK(hipMemcpy(child_move + off, p.t_cmove + src, n * 2, hipMemcpyDeviceToHost));
-            if (child_n) HIPOK(hipMemcpy(child_n + off, p.t_cn + src, n * 4, hipMemcpyDeviceToHost));
-            if (child_q) HIPOK(hipMemcpy(child_q + off, p.t_cq + src, n * 4, hipMemcpyDeviceToHost));
-            if (child_uct) HIPOK(hipMemcpy(child_uct + off, p.t_cu + src, n * 4, hipMemcpyDeviceToHost));
+            const size_t n = (size_t)nch[(size_t)i], r0 = (size_t)i * 224;
+            if (child_move) memcpy(child_move + off, mv.data() + r0, n * 2);
+            if (child_n) memcpy(child_n + off, cn.data() + r0, n * 4);
+            if (child_q) memcpy(child_q + off, cq.data() + r0, n * 4);
+            if (child_uct) memcpy(child_uct + off, cu.data() + r0, n * 4);
             off += (int)n;
         }
     }
