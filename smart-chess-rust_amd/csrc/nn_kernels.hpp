@@ -136,38 +136,44 @@ __global__ __launch_bounds__(256) void k_value_fc1(Fc1Args A) {
     const int kchunk = FC1_K / A.ksplit;  // multiple of 32
     const int steps = kchunk / 32;
     const int row16 = lane & 15, kq = lane >> 4;
-    const bf16_t* arow[4];
-#pragma unroll
-    for (int mt = 0; mt < 4; mt++) {
-        int row = mb * 64 + mt * 16 + row16;
-        if (row >= A.n_pos) row = A.n_pos - 1;
-        arow[mt] = A.hval + (size_t)row * FC1_K + (size_t)ks * kchunk + 8 * kq;
-    }
     const bf16x8* Wv = reinterpret_cast<const bf16x8*>(A.net.wb + A.net.o_fc1) + ((size_t)(ks * steps) * 8 + wave * 2) * 64 + lane;
     f32x4 acc[4][2];
 #pragma unroll
     for (int mt = 0; mt < 4; mt++)
 #pragma unroll
         for (int i = 0; i < 2; i++) acc[mt][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // the kernel is a short dependent chain per workgroup: issue the operand loads of 8 k-steps at a time so
-    // that 48 loads are in flight before the first MFMA (this kernel is latency-, not bandwidth-bound)
+    // The 64 feature rows of the tile are the same for all four waves (each owns 32 of the 128 output columns): they go
+    // through LDS once -- [row][kchunk + 8] bf16, the 16-byte pad keeps the 16 rows of a fragment read on distinct banks --
+    // instead of four times through the CU's 64 B/clk vector-memory path (two thirds of the kernel's operand traffic).
+    __shared__ __attribute__((aligned(16))) bf16_t s_a[64 * (512 + 8)];
+    const int apitch = kchunk + 8;
+    const int pieces = 64 * kchunk / 8;               // 16-byte pieces of the tile
+    for (int c = tid; c < pieces; c += 256) {
+        const int r = c / (kchunk / 8), q = c % (kchunk / 8);
+        int row = mb * 64 + r;
+        if (row >= A.n_pos) row = A.n_pos - 1;
+        *reinterpret_cast<bf16x8*>(s_a + r * apitch + q * 8) =
+            *reinterpret_cast<const bf16x8*>(A.hval + (size_t)row * FC1_K + (size_t)ks * kchunk + q * 8);
+    }
+    // the kernel is a short dependent chain per workgroup: the weight loads of 8 k-steps are issued at a time so that
+    // they are in flight before the first MFMA (this kernel is latency-, not bandwidth-bound)
     for (int s0 = 0; s0 < steps; s0 += 8) {
-        bf16x8 bb[8][2], aa[8][4];
+        bf16x8 bb[8][2];
 #pragma unroll
         for (int u = 0; u < 8; u++) {
             const int s = s0 + u < steps ? s0 + u : steps - 1;
             bb[u][0] = Wv[((size_t)s * 8 + 0) * 64];
             bb[u][1] = Wv[((size_t)s * 8 + 1) * 64];
-#pragma unroll
-            for (int mt = 0; mt < 4; mt++) aa[u][mt] = *reinterpret_cast<const bf16x8*>(arow[mt] + s * 32);
         }
+        if (s0 == 0) __syncthreads();   // A tile staged
 #pragma unroll
         for (int u = 0; u < 8; u++) {
             if (s0 + u < steps) {
 #pragma unroll
                 for (int mt = 0; mt < 4; mt++) {
-                    acc[mt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aa[u][mt], bb[u][0], acc[mt][0], 0, 0, 0);
-                    acc[mt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aa[u][mt], bb[u][1], acc[mt][1], 0, 0, 0);
+                    const bf16x8 a = *reinterpret_cast<const bf16x8*>(s_a + (mt * 16 + row16) * apitch + (s0 + u) * 32 + 8 * kq);
+                    acc[mt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bb[u][0], acc[mt][0], 0, 0, 0);
+                    acc[mt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bb[u][1], acc[mt][1], 0, 0, 0);
                 }
             }
         }
