@@ -680,7 +680,9 @@ int sc_selfplay_create(sc_engine* e, int device_id, const sc_selfplay_config* cf
         p.vf_fc2b = (uint32_t)e->net.f_fc2b;
     }
     sp->reported.assign((size_t)p.trace_cap, 0);
-    sp->fused = e && cfg->evaluator == SC_EVAL_NET && cfg->n_slots <= e->n_cu && !cfg->own_stream;
+    // (the narrow fp8 tower's workgroup is small enough -- 59 KB of LDS, 249 VGPRs -- for two fused workgroups per CU)
+    sp->fused = e && cfg->evaluator == SC_EVAL_NET && !cfg->own_stream &&
+                cfg->n_slots <= e->n_cu * ((e->net.fp8 && e->net.C == 128) ? 2 : 1);
 #ifdef SC_EXP
     if (getenv("SC_FUSED")) sp->fused = getenv("SC_FUSED")[0] != '0';   // experiment builds: A/B
 #endif

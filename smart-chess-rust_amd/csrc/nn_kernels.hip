@@ -37,7 +37,7 @@ const char* nn_init() {
     const void* kn[4] = {reinterpret_cast<const void*>(&K_T32N), reinterpret_cast<const void*>(&K_T32W),
                          reinterpret_cast<const void*>(&K_T8N), reinterpret_cast<const void*>(&K_T8W)};
     for (int i = 0; i < 4; i++) {
-        e = hipFuncSetAttribute(kn[i], hipFuncAttributeMaxDynamicSharedMemorySize, scnn::tower32_lds_bytes(i & 1 ? 256 : 128));
+        e = hipFuncSetAttribute(kn[i], hipFuncAttributeMaxDynamicSharedMemorySize, scnn::tower32_lds_bytes(i & 1 ? 256 : 128, i >= 2));
         if (e != hipSuccess) return hipGetErrorString(e);
     }
 #ifdef SC_EXP
@@ -68,9 +68,9 @@ void tower(const scnn::TowerArgs& a, hipStream_t s) {
     if (a.n_pos <= 0) return;
     const scnn::TowerArgs& b = a;
     if (a.net.tower32 && a.net.fp8 && a.net.C == 128)
-        hipLaunchKernelGGL(K_T8N, dim3(a.n_pos), dim3(256), scnn::tower32_lds_bytes(128), s, b);
+        hipLaunchKernelGGL(K_T8N, dim3(a.n_pos), dim3(256), scnn::tower32_lds_bytes(128, true), s, b);
     else if (a.net.tower32 && a.net.fp8)
-        hipLaunchKernelGGL(K_T8W, dim3(a.n_pos), dim3(256), scnn::tower32_lds_bytes(256), s, b);
+        hipLaunchKernelGGL(K_T8W, dim3(a.n_pos), dim3(256), scnn::tower32_lds_bytes(256, true), s, b);
     else if (a.net.tower32 && a.net.C == 128)
         hipLaunchKernelGGL(K_T32N, dim3(a.n_pos), dim3(256), scnn::tower32_lds_bytes(128), s, b);
     else if (a.net.tower32)
@@ -83,7 +83,7 @@ void tower(const scnn::TowerArgs& a, hipStream_t s) {
 #endif
 }
 void value_fc1(const scnn::Fc1Args& a, hipStream_t s) {
-    if (a.n_pos <= 0) return;
+    if (a.n_pos <= 0 || a.ksplit < 64 || scnn::FC1_K % (a.ksplit * 32)) return;   // the kernel's LDS tile holds K / 64 columns
     hipLaunchKernelGGL(scnn::k_value_fc1, dim3((a.n_pos + 63) / 64, a.ksplit), dim3(256), 0, s, a);
 }
 void value_finish(const scnn::VfinArgs& a, hipStream_t s) {

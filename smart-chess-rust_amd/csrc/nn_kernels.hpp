@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256) void k_value_fc1(Fc1Args A) {
     // The 64 feature rows of the tile are the same for all four waves (each owns 32 of the 128 output columns): they go
     // through LDS once -- [row][kchunk + 8] bf16, the 16-byte pad keeps the 16 rows of a fragment read on distinct banks --
     // instead of four times through the CU's 64 B/clk vector-memory path (two thirds of the kernel's operand traffic).
-    __shared__ __attribute__((aligned(16))) bf16_t s_a[64 * (512 + 8)];
+    __shared__ __attribute__((aligned(16))) bf16_t s_a[64 * (FC1_K / 64 + 8)];   // 33 KB: split-K >= 64 (the launcher checks)
     const int apitch = kchunk + 8;
     const int pieces = 64 * kchunk / 8;               // 16-byte pieces of the tile
     for (int c = tid; c < pieces; c += 256) {

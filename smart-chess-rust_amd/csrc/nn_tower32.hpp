@@ -466,14 +466,15 @@ __device__ __forceinline__ void scale_load(int (&sa)[CT], const NetDev& net, int
         sa[ct] = P::FP8 ? __builtin_bit_cast(int, net.wf[net.f_scales + (size_t)((conv_idx * 8 + wave * CT + ct) * 64 + lane)]) : 127;
 }
 
-// (sized for the bf16 images; the fp8 instantiations use the same budget)
-constexpr int tower32_lds_bytes(int C) {
-    const int xa = 100 * (C + 8) * 2;
-    return xa + 64 * (HEAD + 8) * 2 + 4096 + 3072 + 1024 + 64 + 15 * C * 2;
+// dynamic LDS of a tower workgroup: the haloed image (later the 4672 policy logits), the policy head's image, LayerNorm /
+// SE scratch and the staged per-block parameters.  The e4m3 images are half the size: 49 KB instead of 73 KB at C = 128,
+// which is what lets two fused step workgroups (10 KB of search scratch each) share a CU.
+constexpr int tower32_lds_bytes(int C, bool fp8 = false) {
+    const int psb = C * (fp8 ? 1 : 2) + 16, hpsb = HEAD * (fp8 ? 1 : 2) + 16;
+    const int xa = 100 * psb > 4864 * 4 ? 100 * psb : 4864 * 4;
+    return xa + 64 * hpsb + 4096 + 3072 + 1024 + 64 + 15 * C * 2;
 }
 
-// P: precision policy of the convs; AB: image-fragment buffers of the trunk convs; HRS / H2RS: ring slots of the head convs
-// (their rings hold a wave's whole weight stream).
 // tower_body: the network for position `pos`, run by the 256 threads of one workgroup.  planes_lds: the position's input
 // planes int8[64][112] in LDS, or nullptr: read them from A.boards.
 // Pre (fused step kernel, step_kernels.hip): work that waves 0 and 1 do BEFORE the network -- pre(0) is the game's tree

@@ -63,7 +63,7 @@ const char* step_init() {
                          reinterpret_cast<const void*>(&K_STEP(PrecFP8, 128, SC_T8_RS, SC_T8_TPI, SC_T8_AB)),
                          reinterpret_cast<const void*>(&K_STEP(PrecFP8, 256, SC_T8W_RS, SC_T8W_TPI, SC_T8W_AB))};
     for (int i = 0; i < 4; i++) {
-        hipError_t e = hipFuncSetAttribute(kn[i], hipFuncAttributeMaxDynamicSharedMemorySize, scnn::tower32_lds_bytes(i & 1 ? 256 : 128));
+        hipError_t e = hipFuncSetAttribute(kn[i], hipFuncAttributeMaxDynamicSharedMemorySize, scnn::tower32_lds_bytes(i & 1 ? 256 : 128, i >= 2 && i < 4));
         if (e != hipSuccess) return hipGetErrorString(e);
     }
     return nullptr;
@@ -71,9 +71,9 @@ const char* step_init() {
 void step(const scnn::TowerArgs& a, const sc::SpParams& p, int do_expand, hipStream_t s) {
     const dim3 grid(p.n_slots), block(256);
     if (a.net.fp8 && a.net.C == 128)
-        hipLaunchKernelGGL((K_STEP(PrecFP8, 128, SC_T8_RS, SC_T8_TPI, SC_T8_AB)), grid, block, scnn::tower32_lds_bytes(128), s, a, p, do_expand);
+        hipLaunchKernelGGL((K_STEP(PrecFP8, 128, SC_T8_RS, SC_T8_TPI, SC_T8_AB)), grid, block, scnn::tower32_lds_bytes(128, true), s, a, p, do_expand);
     else if (a.net.fp8)
-        hipLaunchKernelGGL((K_STEP(PrecFP8, 256, SC_T8W_RS, SC_T8W_TPI, SC_T8W_AB)), grid, block, scnn::tower32_lds_bytes(256), s, a, p, do_expand);
+        hipLaunchKernelGGL((K_STEP(PrecFP8, 256, SC_T8W_RS, SC_T8W_TPI, SC_T8W_AB)), grid, block, scnn::tower32_lds_bytes(256, true), s, a, p, do_expand);
     else if (a.net.C == 128)
         hipLaunchKernelGGL((K_STEP(PrecBF16, 128, SC_T32_RS, SC_T32_TPI, SC_T32_AB)), grid, block, scnn::tower32_lds_bytes(128), s, a, p, do_expand);
     else
