@@ -51,6 +51,7 @@ struct sc_engine {
     uint16_t* d_wb = nullptr;
     float* d_wf = nullptr;
     int n_cu = 256;    // compute units of the device
+    int step_blocks_per_cu = 1;   // resident fused step workgroups per CU for this network (1 or 2)
     int ksplit = 64;   // split-K of value_head.ffn.0 (the search kernel's fused tail sums 32 or 64 partials)
     // scratch, grown on demand
     int cap = 0;
@@ -221,6 +222,7 @@ int sc_engine_create(const sc_net_config* cfg, const char* weights_path, int dev
         if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device_id) == hipSuccess && ncu > 0) e->n_cu = ncu;
     }
     static_cast<scnn::NetLayout&>(e->net) = pk.lay;
+    e->step_blocks_per_cu = std::min(2, scl::step_blocks_per_cu(pk.lay));
     e->net.wb = e->d_wb;
     e->net.wf = e->d_wf;
     const int rf = sc_runtime_flags();
@@ -680,9 +682,9 @@ int sc_selfplay_create(sc_engine* e, int device_id, const sc_selfplay_config* cf
         p.vf_fc2b = (uint32_t)e->net.f_fc2b;
     }
     sp->reported.assign((size_t)p.trace_cap, 0);
-    // (the narrow fp8 tower's workgroup is small enough -- 59 KB of LDS, 249 VGPRs -- for two fused workgroups per CU)
-    sp->fused = e && cfg->evaluator == SC_EVAL_NET && !cfg->own_stream &&
-                cfg->n_slots <= e->n_cu * ((e->net.fp8 && e->net.C == 128) ? 2 : 1);
+    // (the narrow fp8 tower's workgroup is small enough -- 59 KB of LDS, 249 VGPRs -- for two fused workgroups per CU; the
+    // runtime's occupancy answer is used, capped at 2: a third would leave CUs empty at 512 games.  The bf16 one is not.)
+    sp->fused = e && cfg->evaluator == SC_EVAL_NET && !cfg->own_stream && cfg->n_slots <= e->n_cu * e->step_blocks_per_cu;
 #ifdef SC_EXP
     if (getenv("SC_FUSED")) sp->fused = getenv("SC_FUSED")[0] != '0';   // experiment builds: A/B
 #endif

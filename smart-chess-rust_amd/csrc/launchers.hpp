@@ -26,6 +26,7 @@ void tower(const scnn::TowerArgs& a, hipStream_t s);
 void value_fc1(const scnn::Fc1Args& a, hipStream_t s);
 // step_kernels.hip: search wave + tower in one launch (slot g = position g; a.n_pos must equal p.n_slots)
 const char* step_init();
+int step_blocks_per_cu(const scnn::NetLayout& net);
 void step(const scnn::TowerArgs& a, const sc::SpParams& p, int do_expand, hipStream_t s);
 void value_finish(const scnn::VfinArgs& a, hipStream_t s);
 }  // namespace scl

@@ -68,6 +68,21 @@ const char* step_init() {
     }
     return nullptr;
 }
+// fused workgroups that can be resident on one CU (registers + LDS, asked of the runtime): the engine uses the fused form
+// only when every game's workgroup is resident at once
+int step_blocks_per_cu(const scnn::NetLayout& net) {
+    int n = 0;
+    hipError_t e;
+    if (net.fp8 && net.C == 128)
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, K_STEP(PrecFP8, 128, SC_T8_RS, SC_T8_TPI, SC_T8_AB), 256, scnn::tower32_lds_bytes(128, true));
+    else if (net.fp8)
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, K_STEP(PrecFP8, 256, SC_T8W_RS, SC_T8W_TPI, SC_T8W_AB), 256, scnn::tower32_lds_bytes(256, true));
+    else if (net.C == 128)
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, K_STEP(PrecBF16, 128, SC_T32_RS, SC_T32_TPI, SC_T32_AB), 256, scnn::tower32_lds_bytes(128));
+    else
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, K_STEP(PrecBF16, 256, SC_T32W_RS, SC_T32W_TPI, SC_T32_AB), 256, scnn::tower32_lds_bytes(256));
+    return e == hipSuccess && n > 0 ? n : 1;
+}
 void step(const scnn::TowerArgs& a, const sc::SpParams& p, int do_expand, hipStream_t s) {
     const dim3 grid(p.n_slots), block(256);
     if (a.net.fp8 && a.net.C == 128)
