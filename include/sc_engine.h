@@ -183,7 +183,8 @@ typedef struct {
     int64_t nn_evals;        /* leaf evaluations that needed the network */
     int32_t games_finished;
     int32_t games_active;
-    int32_t error_flags;     /* non-finite PUCT value etc. (reference panics: src/mcts.rs:202-214) */
+    int32_t error_flags;     /* bit mask: 1 non-finite PUCT value (reference panics: src/mcts.rs:202-214), 2 node pool overflow,
+                                4 move without action index, 8 descent deeper than the path buffer, 16 internal hand-off timeout */
     int32_t plies_done;      /* total plies played over all games */
 } sc_selfplay_stats;
 int sc_selfplay_get_stats(sc_selfplay*, sc_selfplay_stats* out);

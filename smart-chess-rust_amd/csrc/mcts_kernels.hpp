@@ -337,6 +337,7 @@ __device__ __forceinline__ void dev_encode_helper(const SpParams& p, int g, int 
         if (st == 0) __builtin_amdgcn_s_sleep(2);
     }
     st = __builtin_amdgcn_readfirstlane(st);
+    if (st == 0 && lane == 0) atomicOr(&p.cnt->err, ERR_HELPER_TIMEOUT);   // never seen: the search wave posts on every path
     if (st != 1) return;
     wave_sync();
     const int idx = __builtin_amdgcn_readfirstlane(box->idx), root_ply = __builtin_amdgcn_readfirstlane(box->root_ply);
