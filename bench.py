@@ -268,9 +268,9 @@ def main():
     ap.add_argument("--no-alt", dest="alt", action="store_false", help="skip the short extra runs (steady state, other width, 2x games, fp8)")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp8"], help="network precision of the main run (BASELINE configs[1]: bf16)")
     ap.add_argument("--groups", type=int, default=1, help="split the games of a GPU into K groups on K HIP streams (overlap)")
-    ap.add_argument("--timing-stride", type=int, default=8,
-                    help="every n-th tower launch is bracketed by a HIP event pair for the roofline figure (an event pair per "
-                         "launch breaks the back-to-back dispatch of the step's three kernels and costs ~3 %% of throughput)")
+    ap.add_argument("--timing-stride", type=int, default=32,
+                    help="every n-th simulation step runs as separate launches with the tower bracketed by a HIP event pair for the "
+                         "roofline figure (the other steps use the fused step kernel; a timed step is ~5 us slower)")
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU work for cpu_baseline (0 = skip)")
     ap.add_argument("--cpu-dry-run", action="store_true",
                     help="HARNESS TEST ONLY (gloo, no GPU): exercises sharding/timing/aggregation with the oracle's "
