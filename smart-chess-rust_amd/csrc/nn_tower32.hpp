@@ -545,7 +545,12 @@ __device__ __forceinline__ void tower_body(const TowerArgs& A, const int pos, co
     f32x4 spv = f32x4{0.f, 0.f, 0.f, 0.f};
     if (tid < 3 * C / 4) spv = *reinterpret_cast<const f32x4*>(net.wf + net.f_stem + tid * 4);
     else if (tid < C) spv = *reinterpret_cast<const f32x4*>(net.wf + net.f_blocks + (tid - 3 * C / 4) * 4);
-    ring_fill<P, CT, TILES, RS>(ring, net.wb + net.o_stem, wave, lane);   // the stem's first weights too
+    // the stem's first weights too -- except for the fused kernel's search wave: its first loads are the search's (a wave's
+    // loads return in order: the control block would queue behind 12 KB of weights); it fills its ring after the search
+#ifndef SC_FUSED_RING_LATE
+#define SC_FUSED_RING_LATE 1   // experiment builds: 0 = the search wave also requests its weights first
+#endif
+    if (!FUSED || wave != 0 || !SC_FUSED_RING_LATE) ring_fill<P, CT, TILES, RS>(ring, net.wb + net.o_stem, wave, lane);
     __builtin_amdgcn_sched_barrier(0);
     // ---- zero the image (halo stays zero for the whole kernel), then write the 112 input planes
     if constexpr (FUSED) {
@@ -553,6 +558,7 @@ __device__ __forceinline__ void tower_body(const TowerArgs& A, const int pos, co
         if (wave <= 1) {   // wave 0: the search; wave 1: its helper (plane encoding)
             const bool go = pre(wave);
             if (wave == 0 && lane == 0) s_go = go ? 1 : 0;
+            if (wave == 0 && SC_FUSED_RING_LATE) ring_fill<P, CT, TILES, RS>(ring, net.wb + net.o_stem, wave, lane);
         } else {
             uint4* z = reinterpret_cast<uint4*>(smem);
             for (int k = tid - 128; k < 100 * PSB / 16; k += 128) z[k] = make_uint4(0, 0, 0, 0);
