@@ -152,3 +152,20 @@ def test_fp8_selfplay_is_deterministic_and_legal(scamd, orc):
             assert [k[0] for k in kids] == st.legal_uci() and sum(k[1] for k in kids) == 23
             st.push(mv)
     eng.close()
+
+
+@pytest.mark.parametrize("slots,games,R", [(1, 2, 5), (300, 340, 4), (513, 513, 3)])
+def test_fp8_selfplay_edge_configurations(scamd, slots, games, R):
+    """one slot; more slots than CUs (the narrow fp8 tower runs two fused workgroups per CU up to 512 slots); more than
+    that (separate launches): every game finishes, every ply's visits add up"""
+    eng = scamd.Engine(2, 128, seed=1, precision="fp8")
+    sp = scamd.SelfPlay(eng, n_slots=slots, n_games=games, rollout_num=R, num_steps=3, temperature=0.0, temperature_switch=1, with_noise=True,
+                        seed=3, outcome_gate=0)
+    sp.run()
+    st = sp.stats()
+    assert st["games_finished"] == games and st["error_flags"] == 0 and st["games_active"] == 0
+    for g in range(0, games, 7):
+        t = sp.trace(g)
+        assert t is not None and 1 <= len(t["steps"]) <= 3 and all(sum(c[1] for c in s[2]) == R - 1 for s in t["steps"])
+    sp.close()
+    eng.close()
