@@ -184,7 +184,7 @@ typedef struct {
     int32_t games_finished;
     int32_t games_active;
     int32_t error_flags;     /* bit mask: 1 non-finite PUCT value (reference panics: src/mcts.rs:202-214), 2 node pool overflow,
-                                4 move without action index, 8 descent deeper than the path buffer, 16 internal hand-off timeout */
+                                4 move without action index, 8 descent deeper than the path buffer, 16 / 32 internal hand-off timeout (search helper / value-head tiles) */
     int32_t plies_done;      /* total plies played over all games */
 } sc_selfplay_stats;
 int sc_selfplay_get_stats(sc_selfplay*, sc_selfplay_stats* out);

@@ -530,6 +530,9 @@ struct sc_selfplay {
     // launch is what hides under another group's tower (measured: 512 games 3.48 M vs 3.02 M simulations/s at fp8, two
     // groups of 256 2.65 M vs 2.38 M at bf16, in favour of the separate launches)
     bool fused = false;
+    bool fc1_in_step = false;        // ... and value_head.ffn.0 runs inside that launch too (one launch per simulation step)
+    uint32_t* d_fc1_ctr = nullptr;   // its arrival counters, one per 64-position block, 128 B apart (monotonic)
+    uint32_t fc1_launches = 0;       // step launches that counted on them so far
 };
 
 // complete the last enqueued simulation (expand / backward / ply transition) so that host reads see a
@@ -668,6 +671,7 @@ int sc_selfplay_create(sc_engine* e, int device_id, const sc_selfplay_config* cf
     if (e && cfg->evaluator == SC_EVAL_NET) {
         rc |= sp_alloc(sp, &sp->d_hval, G * 64 * 256);
         rc |= sp_alloc(sp, &sp->d_vpart, (size_t)e->ksplit * G * 128);
+        rc |= sp_alloc(sp, &sp->d_fc1_ctr, (G + 63) / 64 * 32);
         if (rc) {
             sc_selfplay_destroy(sp);
             return fail("self-play allocation failed", -2);
@@ -687,6 +691,12 @@ int sc_selfplay_create(sc_engine* e, int device_id, const sc_selfplay_config* cf
     sp->fused = e && cfg->evaluator == SC_EVAL_NET && !cfg->own_stream && cfg->n_slots <= e->n_cu * e->step_blocks_per_cu;
 #ifdef SC_EXP
     if (getenv("SC_FUSED")) sp->fused = getenv("SC_FUSED")[0] != '0';   // experiment builds: A/B
+#endif
+    // One launch per step: value_head.ffn.0's 64-position tiles are computed by the step kernel's own workgroups (workgroup g:
+    // tile (g / 64, K chunk g % 64), step_kernels.hip) -- when the slots fill whole blocks and the split is the kernel's 64.
+    sp->fc1_in_step = sp->fused && cfg->n_slots % 64 == 0 && e->ksplit == 64;
+#ifdef SC_FC1_IN_STEP_OFF   // A/B builds
+    sp->fc1_in_step = false;
 #endif
     // the zero-fills above ran on the NULL stream, which does not order against the (non-blocking) launch
     // stream: make them complete before the first kernel touches the buffers
@@ -764,14 +774,22 @@ int sc_selfplay_enqueue_sims(sc_selfplay* sp, int n) {
             t.hval = sp->d_hval;
             t.dbg = nullptr;
             t.dbg_stage = -1;
-            scl::step(t, q, 1, s);
-            scnn::Fc1Args f{};
-            f.net = e->net;
-            f.n_pos = p.n_slots;
-            f.ksplit = e->ksplit;
-            f.hval = sp->d_hval;
-            f.vpart = sp->d_vpart;
-            scl::value_fc1(f, s);
+            if (sp->fc1_in_step) {
+                t.fc1_arrive = sp->d_fc1_ctr;
+                t.fc1_target = 64u * ++sp->fc1_launches;   // every workgroup of a block arrives once per launch (wraps with the counter)
+                t.vpart = sp->d_vpart;
+                t.fc1_acquire = e->step_blocks_per_cu > 1;
+                scl::step(t, q, 1, s);
+            } else {
+                scl::step(t, q, 1, s);
+                scnn::Fc1Args f{};
+                f.net = e->net;
+                f.n_pos = p.n_slots;
+                f.ksplit = e->ksplit;
+                f.hval = sp->d_hval;
+                f.vpart = sp->d_vpart;
+                scl::value_fc1(f, s);
+            }
             sp->nn_launches++;
             continue;
         }

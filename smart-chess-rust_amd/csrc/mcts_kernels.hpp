@@ -868,8 +868,8 @@ __device__ __forceinline__ float value_tail_finish(const SpParams& p, const Valu
         s0 += m[k] * t.wm[k].x;
         s1 += m[k] * t.wm[k].y;
     }
-    s0 = s0 > 0.f ? s0 : 0.f;
-    s1 = s1 > 0.f ? s1 : 0.f;
+    s0 = s0 < 0.f ? 0.f : s0;   // ReLU that keeps a NaN (torch.relu does; `s > 0 ? s : 0` would swallow it)
+    s1 = s1 < 0.f ? 0.f : s1;
     float part = s0 * t.w2.x + s1 * t.w2.y;
     part = wave_sum_f_dpp(part);   // same order as k_value_finish (nn_kernels.hpp: wave_sum64)
     float v = tanhf(part + t.fc2b);

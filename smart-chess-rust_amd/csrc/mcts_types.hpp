@@ -11,7 +11,7 @@ enum { ST_IDLE = 0, ST_ACTIVE = 1, ST_FINISHED = 2, ST_PENDING = 3 };   // PENDI
 enum { TR_FREE = 0, TR_LIVE = 1, TR_DONE = 2 };   // TraceHdr::state
 enum { SYNTH_HASH = 1, SYNTH_COARSE = 2, SYNTH_UNIFORM = 3 };   // SpParams::evaluator of the synthetic evaluators (sc_engine.h)
 enum { LK_NONE = 0, LK_EVAL = 1, LK_TERM_NEW = 2, LK_TERM_CACHED = 3 };
-enum { ERR_NONFINITE_UCT = 1, ERR_POOL_OVERFLOW = 2, ERR_BAD_MOVE_INDEX = 4, ERR_DEPTH_OVERFLOW = 8, ERR_HELPER_TIMEOUT = 16 };
+enum { ERR_NONFINITE_UCT = 1, ERR_POOL_OVERFLOW = 2, ERR_BAD_MOVE_INDEX = 4, ERR_DEPTH_OVERFLOW = 8, ERR_HELPER_TIMEOUT = 16, ERR_HANDOFF_TIMEOUT = 32 };
 
 struct GameCtl {
     int32_t status, ply, sim, n_nodes, n_exp;

@@ -125,56 +125,86 @@ __device__ __forceinline__ void vec_mma(const bf16_t* x, const VecW<K, NTW>& v, 
 template <int NTW>
 __device__ inline int chan0(int wave, int lane) { return wave * (16 * NTW) + (lane & 15) * NTW; }
 
-#ifndef SC_NO_KERNELS
 // --------------------------------------------------------------------------------------------
-// value_head.ffn.0 (Linear 16391->128) over the whole batch: out[b][j] = sum_k hval[b][k] W[k][j].
-// grid = (ceil(n/64), KSPLIT); block 256 = 4 waves, wave w owns column tiles 2w, 2w+1.
-// Partial sums go to vpart[ksplit][b][128]; k_value_finish reduces them in fixed order.
-__global__ __launch_bounds__(256) void k_value_fc1(Fc1Args A) {
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int mb = blockIdx.x, ks = blockIdx.y;
-    const int kchunk = FC1_K / A.ksplit;  // multiple of 32
-    const int steps = kchunk / 32;
+// value_head.ffn.0 (Linear 16391->128) over the batch: out[b][j] = sum_k hval[b][k] W[k][j], one 64-position x K/ksplit
+// tile per workgroup (256 threads = 4 waves, wave w owns column tiles 2w, 2w+1); partial sums go to
+// vpart[ksplit][b][128] and the search kernel's value tail reduces them in fixed order.  The tile is three device
+// functions because it has two callers: k_value_fc1 (its own launch) and the tail of the fused step kernel
+// (step_kernels.hip), which requests the weights BEFORE it waits for the other workgroups' feature rows.
+// Split-K >= 64 (the launchers check): a tile is at most 8 k-steps and its weights fit one register batch.
+constexpr int AUX_SC1 = 16;   // cache-policy bits of the gfx942/gfx950 buffer builtins: 1 = sc0, 2 = nt, 16 = sc1
+struct Fc1W {
+    bf16x8 b[8][2];
+};
+constexpr int FC1_TILE_LDS = 64 * (FC1_K / 64 + 8) * 2;   // bytes of the staged feature rows (33 KB)
+__device__ __forceinline__ void fc1_wload(Fc1W& w, const NetDev& net, int ks, int ksplit, int wave, int lane) {
+    const int steps = FC1_K / ksplit / 32;
+    const bf16x8* Wv = reinterpret_cast<const bf16x8*>(net.wb + net.o_fc1) + ((size_t)(ks * steps) * 8 + wave * 2) * 64 + lane;
+    // the tile is a short dependent chain: all its weight loads are in flight before the first MFMA
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+        const int s = u < steps ? u : steps - 1;
+        w.b[u][0] = Wv[((size_t)s * 8 + 0) * 64];
+        w.b[u][1] = Wv[((size_t)s * 8 + 1) * 64];
+    }
+}
+// The 64 feature rows of the tile are the same for all four waves (each owns 32 of the 128 output columns): they go
+// through LDS once -- [row][kchunk + 8] bf16, the 16-byte pad keeps the 16 rows of a fragment read on distinct banks --
+// instead of four times through the CU's 64 B/clk vector-memory path (two thirds of the tile's operand traffic).
+// SC1: the rows were published by other workgroups of the SAME launch (write-through stores): load them past this CU's L1.
+template <bool SC1>
+__device__ __forceinline__ void fc1_stage_a(bf16_t* s_a, const bf16_t* hval, int n_pos, int mb, int ks, int ksplit, int tid) {
+    typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+    const int kchunk = FC1_K / ksplit;  // multiple of 32
+    const int apitch = kchunk + 8;
+    const int pieces = 64 * kchunk / 8;               // 16-byte pieces of the tile
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(hval) + (size_t)mb * 64 * FC1_K, 0, 0x7fffffff, 0x00020000);
+    const int last = n_pos - 1 - mb * 64;             // rows past the batch repeat the last one (their results are not stored)
+    for (int c = tid; c < pieces; c += 256) {
+        const int r = c / (kchunk / 8), q = c % (kchunk / 8);
+        const int row = r < last ? r : last;
+        const int off = (row * FC1_K + ks * kchunk + q * 8) * 2;
+        const u32x4 v = SC1 ? __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, AUX_SC1) : __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
+        *reinterpret_cast<u32x4*>(s_a + r * apitch + q * 8) = v;
+    }
+}
+// the same in two halves for split-K 64 and a full block of 64 rows (the fused step kernel): the loads (sc1) into registers ...
+__device__ __forceinline__ void fc1_load_a(__attribute__((ext_vector_type(4))) unsigned int (&a)[8], const bf16_t* hval, int mb, int ks, int tid) {
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(hval) + (size_t)mb * 64 * FC1_K, 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const int c = tid + 256 * k, r = c >> 5, q = c & 31;
+        a[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (r * FC1_K + ks * 256 + q * 8) * 2, 0, AUX_SC1);
+    }
+}
+// ... and their way into the staging tile
+__device__ __forceinline__ void fc1_put_a(bf16_t* s_a, const __attribute__((ext_vector_type(4))) unsigned int (&a)[8], int tid) {
+    typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const int c = tid + 256 * k, r = c >> 5, q = c & 31;
+        *reinterpret_cast<u32x4*>(s_a + r * (256 + 8) + q * 8) = a[k];
+    }
+}
+__device__ __forceinline__ void fc1_mma_store(const Fc1W& w, const bf16_t* s_a, float* vpart, int n_pos, int mb, int ks, int ksplit,
+                                              int wave, int lane) {
+    const int kchunk = FC1_K / ksplit, steps = kchunk / 32, apitch = kchunk + 8;
     const int row16 = lane & 15, kq = lane >> 4;
-    const bf16x8* Wv = reinterpret_cast<const bf16x8*>(A.net.wb + A.net.o_fc1) + ((size_t)(ks * steps) * 8 + wave * 2) * 64 + lane;
     f32x4 acc[4][2];
 #pragma unroll
     for (int mt = 0; mt < 4; mt++)
 #pragma unroll
         for (int i = 0; i < 2; i++) acc[mt][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // The 64 feature rows of the tile are the same for all four waves (each owns 32 of the 128 output columns): they go
-    // through LDS once -- [row][kchunk + 8] bf16, the 16-byte pad keeps the 16 rows of a fragment read on distinct banks --
-    // instead of four times through the CU's 64 B/clk vector-memory path (two thirds of the kernel's operand traffic).
-    __shared__ __attribute__((aligned(16))) bf16_t s_a[64 * (FC1_K / 64 + 8)];   // 33 KB: split-K >= 64 (the launcher checks)
-    const int apitch = kchunk + 8;
-    const int pieces = 64 * kchunk / 8;               // 16-byte pieces of the tile
-    for (int c = tid; c < pieces; c += 256) {
-        const int r = c / (kchunk / 8), q = c % (kchunk / 8);
-        int row = mb * 64 + r;
-        if (row >= A.n_pos) row = A.n_pos - 1;
-        *reinterpret_cast<bf16x8*>(s_a + r * apitch + q * 8) =
-            *reinterpret_cast<const bf16x8*>(A.hval + (size_t)row * FC1_K + (size_t)ks * kchunk + q * 8);
-    }
-    // the kernel is a short dependent chain per workgroup: the weight loads of 8 k-steps are issued at a time so that
-    // they are in flight before the first MFMA (this kernel is latency-, not bandwidth-bound)
-    for (int s0 = 0; s0 < steps; s0 += 8) {
-        bf16x8 bb[8][2];
 #pragma unroll
-        for (int u = 0; u < 8; u++) {
-            const int s = s0 + u < steps ? s0 + u : steps - 1;
-            bb[u][0] = Wv[((size_t)s * 8 + 0) * 64];
-            bb[u][1] = Wv[((size_t)s * 8 + 1) * 64];
-        }
-        if (s0 == 0) __syncthreads();   // A tile staged
+    for (int u = 0; u < 8; u++) {
+        if (u < steps) {
 #pragma unroll
-        for (int u = 0; u < 8; u++) {
-            if (s0 + u < steps) {
-#pragma unroll
-                for (int mt = 0; mt < 4; mt++) {
-                    const bf16x8 a = *reinterpret_cast<const bf16x8*>(s_a + (mt * 16 + row16) * apitch + (s0 + u) * 32 + 8 * kq);
-                    acc[mt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bb[u][0], acc[mt][0], 0, 0, 0);
-                    acc[mt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bb[u][1], acc[mt][1], 0, 0, 0);
-                }
+            for (int mt = 0; mt < 4; mt++) {
+                const bf16x8 a = *reinterpret_cast<const bf16x8*>(s_a + (mt * 16 + row16) * apitch + u * 32 + 8 * kq);
+                acc[mt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, w.b[u][0], acc[mt][0], 0, 0, 0);
+                acc[mt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, w.b[u][1], acc[mt][1], 0, 0, 0);
             }
         }
     }
@@ -183,11 +213,23 @@ __global__ __launch_bounds__(256) void k_value_fc1(Fc1Args A) {
     for (int mt = 0; mt < 4; mt++)
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-            int row = mb * 64 + mt * 16 + (lane >> 4) * 4 + r;
-            if (row < A.n_pos)
-                *reinterpret_cast<float2*>(A.vpart + ((size_t)ks * A.n_pos + row) * FC1_N + c0) =
-                    make_float2(acc[mt][0][r], acc[mt][1][r]);
+            const int row = mb * 64 + mt * 16 + (lane >> 4) * 4 + r;
+            if (row < n_pos)
+                *reinterpret_cast<float2*>(vpart + ((size_t)ks * n_pos + row) * FC1_N + c0) = make_float2(acc[mt][0][r], acc[mt][1][r]);
         }
+}
+
+#ifndef SC_NO_KERNELS
+// grid = (ceil(n/64), KSPLIT)
+__global__ __launch_bounds__(256) void k_value_fc1(Fc1Args A) {
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int mb = blockIdx.x, ks = blockIdx.y;
+    __shared__ __attribute__((aligned(16))) bf16_t s_a[FC1_TILE_LDS / 2];
+    Fc1W w;
+    fc1_wload(w, A.net, ks, A.ksplit, wave, lane);
+    fc1_stage_a<false>(s_a, A.hval, A.n_pos, mb, ks, A.ksplit, tid);
+    __syncthreads();   // A tile staged
+    fc1_mma_store(w, s_a, A.vpart, A.n_pos, mb, ks, A.ksplit, wave, lane);
 }
 
 // value head tail (py/module.py:95-106,147-149): + meta columns + bias, ReLU, Linear 128->1, tanh,
@@ -215,8 +257,8 @@ __global__ __launch_bounds__(64) void k_value_finish(VfinArgs A) {
         s0 = __fadd_rn(s0, __fmul_rn(m[k], w.x));   // no FMA contraction: the fused tail is built with -ffp-contract=off
         s1 = __fadd_rn(s1, __fmul_rn(m[k], w.y));
     }
-    s0 = s0 > 0.f ? s0 : 0.f;
-    s1 = s1 > 0.f ? s1 : 0.f;
+    s0 = s0 < 0.f ? 0.f : s0;   // ReLU that keeps a NaN (torch.relu does; `s > 0 ? s : 0` would swallow it)
+    s1 = s1 < 0.f ? 0.f : s1;
     const float2 w2 = *reinterpret_cast<const float2*>(wf + A.net.f_fc2w + j);
     float part = __fadd_rn(__fmul_rn(s0, w2.x), __fmul_rn(s1, w2.y));
     part = wave_sum64(part);   // same DPP order as the fused tail in the search kernel (mcts_kernels.hpp: wave_sum_f_dpp)

@@ -484,9 +484,21 @@ constexpr int tower32_lds_bytes(int C, bool fp8 = false) {
 struct NoPre {
     __device__ __forceinline__ bool operator()(int) const { return true; }
 };
-template <class P, int C, int RS, int TPI, int AB = SC_T32_AB, class Pre = NoPre>
-__device__ __forceinline__ void tower_body(const TowerArgs& A, const int pos, const int8_t* planes_lds, Pre pre = Pre()) {
+// value_head.ffn.0 inside the fused step launch (step_kernels.hip: fc1_tail; HAND && A.fc1_arrive): what the tower requests
+// ahead of the tail, under its softmax -- the tile's weights and a first reading of the block's arrival counter
+struct Fc1Hand {
+    typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+    Fc1W w;
+    uint32_t early;   // lane 0 of wave 0: a reading of the block's arrival counter taken under the softmax
+    int have_a;       // the first reading (taken under the last policy conv) already showed the block complete:
+    u32x4 a[8];       // ... this thread's 8 pieces of the 64 feature rows, requested under the softmax too
+};
+struct NoHand {};
+template <class P, int C, int RS, int TPI, int AB = SC_T32_AB, class Pre = NoPre, class Hand = NoHand>
+__device__ __forceinline__ bool tower_body(const TowerArgs& A, const int pos, const int8_t* planes_lds, Pre pre, Hand& fhr) {
     constexpr bool FUSED = !std::is_same<Pre, NoPre>::value;
+    constexpr bool HAND = std::is_same<Hand, Fc1Hand>::value;   // value_head.ffn.0 inside this launch is possible (A.fc1_arrive says)
+    Hand* const fh = &fhr;
     typedef typename P::frag frag;
     constexpr int CT = C / 128;        // 32-channel tiles per wave in the trunk
     constexpr int TILES = C / 32;
@@ -564,7 +576,7 @@ __device__ __forceinline__ void tower_body(const TowerArgs& A, const int pos, co
             for (int k = tid - 128; k < 100 * PSB / 16; k += 128) z[k] = make_uint4(0, 0, 0, 0);
         }
         __syncthreads();   // image zeroed; planes in planes_lds, legal moves / indices stored (the barrier waits for wave 0's stores)
-        if (!s_go) return; // terminal leaf or idle slot: no network evaluation this step
+        if (!s_go) return false; // terminal leaf or idle slot: no network evaluation this step
     } else {
         uint4* z = reinterpret_cast<uint4*>(smem);
         for (int k = tid; k < 100 * PSB / 16; k += 256) z[k] = make_uint4(0, 0, 0, 0);
@@ -850,7 +862,8 @@ __device__ __forceinline__ void tower_body(const TowerArgs& A, const int pos, co
 #pragma unroll
                 for (int r = 0; r < 16; r++) hv[ct][pt][r] += Bv.v[ct][r >> 2][r & 3];
         LnStat L;
-        ln_reduce<2>(hv, L, HEAD, wave, lane, s_stat, ln_parity, bad SC_STAMP_PASS(21));
+        int badv = bad;   // the trunk's NaNs and this head's own: the policy head below does not inherit the latter
+        ln_reduce<2>(hv, L, HEAD, wave, lane, s_stat, ln_parity, badv SC_STAMP_PASS(21));
         ch_load_lds<2>(G, HP_V + HEAD * 4, wave, h);
         ch_load_lds<2>(E, HP_V + 2 * HEAD * 4, wave, h);
         ln_apply<2>(hv, L, G, E, true);
@@ -858,15 +871,26 @@ __device__ __forceinline__ void tower_body(const TowerArgs& A, const int pos, co
         // Feature order in HBM = accumulator order ([wave][ct][pt][lane][16 registers], weights.hpp packs the rows of
         // value_head.ffn.0 to match): a lane's 16 values are 32 contiguous bytes and a wave's two stores fill whole
         // cache lines.  Writing [pixel][channel] rows from this layout (8 bytes per lane, 512 B apart) cost 4.6 k cycles.
+        // A NaN LayerNorm variance so far (trunk or value head, see LnStat) poisons the lane's features and through them
+        // the value; one in the policy head (below) poisons the priors only -- separate heads, as in py/module.py:136-152.
+        // With value_head.ffn.0 inside this launch (A.fc1_arrive) the rows are read by OTHER workgroups of the launch:
+        // write-through (sc1) stores, drained before the arrival below.
+        const __amdgpu_buffer_rsrc_t hrs = __builtin_amdgcn_make_buffer_rsrc(A.hval + (size_t)pos * (64 * HEAD), 0, 0x7fffffff, 0x00020000);
+        const bool wt = HAND && A.fc1_arrive;
 #pragma unroll
         for (int ct = 0; ct < 2; ct++)
 #pragma unroll
             for (int pt = 0; pt < 2; pt++) {
-                bf16_t* dst = A.hval + (size_t)pos * (64 * HEAD) + (size_t)(((wave * 2 + ct) * 2 + pt) * 64 + lane) * 16;
+                const int off = (((wave * 2 + ct) * 2 + pt) * 64 + lane) * 32;
 #pragma unroll
-                for (int q = 0; q < 2; q++)
-                    *reinterpret_cast<uint4*>(dst + 8 * q) = make_uint4(pk_bf16(pair(hv[ct][pt], 8 * q)), pk_bf16(pair(hv[ct][pt], 8 * q + 2)),
-                                                                       pk_bf16(pair(hv[ct][pt], 8 * q + 4)), pk_bf16(pair(hv[ct][pt], 8 * q + 6)));
+                for (int q = 0; q < 2; q++) {
+                    typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+                    u32x4 v = {pk_bf16(pair(hv[ct][pt], 8 * q)), pk_bf16(pair(hv[ct][pt], 8 * q + 2)), pk_bf16(pair(hv[ct][pt], 8 * q + 4)),
+                               pk_bf16(pair(hv[ct][pt], 8 * q + 6))};
+                    if (badv) v = u32x4{0x7fc07fc0u, 0x7fc07fc0u, 0x7fc07fc0u, 0x7fc07fc0u};
+                    if (wt) __builtin_amdgcn_raw_buffer_store_b128(v, hrs, off + 16 * q, 0, AUX_SC1);
+                    else __builtin_amdgcn_raw_buffer_store_b128(v, hrs, off + 16 * q, 0, 0);
+                }
             }
     }
     SC_MARK(16);
@@ -878,10 +902,16 @@ __device__ __forceinline__ void tower_body(const TowerArgs& A, const int pos, co
         acc_init<2>(hp, Bv);
         conv_mma32<P, C, 1, 2, 8, PSB, HRS, 1, true, HAB>(0, net.wb + net.o_pconv1, wave, lane, px, hp, hr, 0, sh);
         SC_MARK(24);
+        // value_head.ffn.0 inside this launch: this wave's feature stores (a conv ago) have left the CU ...
+        if (HAND && A.fc1_arrive) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         ring_fill<P, 1, 4, H2RS>(hr2, net.wb + net.o_pconv2, wave, lane);   // hidden under the LayerNorm
         __builtin_amdgcn_sched_barrier(0);
         LnStat L;
         ln_reduce<2>(hp, L, HEAD, wave, lane, s_stat, ln_parity, bad SC_STAMP_PASS(25));
+        // ... and, behind the LayerNorm's barrier, so have the other waves': one lane signals for the whole workgroup
+        // (MI355X_MICROARCH.md, hand-off forms, row 1)
+        if (HAND && A.fc1_arrive && tid == 0)
+            __hip_atomic_fetch_add(A.fc1_arrive + (pos >> 6) * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         ch_load_lds<2>(G, HP_P1 + HEAD * 4, wave, h);
         ch_load_lds<2>(E, HP_P1 + 2 * HEAD * 4, wave, h);
         ln_apply<2>(hp, L, G, E, false);
@@ -899,6 +929,10 @@ __device__ __forceinline__ void tower_body(const TowerArgs& A, const int pos, co
         const int pxh[2] = {gpb[0] + h * P::FB, gpb[1] + h * P::FB};
         conv_mma32<P, HEAD, 1, 1, 4, HPSB, H2RS, 1, true, H2AB>(XA_BYTES, net.wb + net.o_pconv2, wave, lane, pxh, z, hr2, 0, sh2);
         SC_MARK(28);
+        // first reading of the block's arrival counter (judged at the barrier in front of the softmax, a round trip later)
+        uint32_t first = 0;
+        if (HAND && A.fc1_arrive && tid == 0 && !A.fc1_acquire)
+            first = __hip_atomic_load(A.fc1_arrive + (pos >> 6) * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // padded channels (>=73) have zero weights, bias, gamma, beta: they add 0 to both LN sums
         LnStat L;
         ln_reduce<1>(z, L, 73, wave, lane, s_stat, ln_parity, bad SC_STAMP_PASS(29));
@@ -915,13 +949,19 @@ __device__ __forceinline__ void tower_body(const TowerArgs& A, const int pos, co
                 const int ch = chan32<1>(wave, 0, r >> 2, h) + (r & 3);
                 if (ch < 73) s_z[ch * 64 + bp[pt]] = z[0][pt][r];  // Flatten is channel-major (module.py:75)
             }
-        if (bad) {   // see LnStat: make the NaN visible in the priors and (through the value features) in the value
-            s_z[lane] = __builtin_nanf("");
-            A.hval[(size_t)pos * 64 * HEAD + tid] = 0x7fc0;
-        }
+        if (bad) s_z[lane] = __builtin_nanf("");   // see LnStat: make the NaN visible in the priors
+        if (HAND && A.fc1_arrive && tid == 0) reinterpret_cast<int*>(s_red)[8] = !A.fc1_acquire && (int32_t)(first - A.fc1_target) >= 0;
     }
     __syncthreads();
     SC_MARK(18);
+    if constexpr (HAND) {
+        if (A.fc1_arrive) {   // the tail's first round trips fly under the softmax
+            fc1_wload(fh->w, net, pos & 63, 64, wave, lane);
+            fh->have_a = reinterpret_cast<const int*>(s_red)[8];
+            if (fh->have_a) fc1_load_a(fh->a, A.hval, pos >> 6, pos & 63, tid);   // the polling lane's reading matched in front of the barrier
+            else if (tid == 0) fh->early = __hip_atomic_load(A.fc1_arrive + (pos >> 6) * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
     // ---- log_softmax over 4672 (module.py:80), then the legal-move gather of torch.rs:148-175
     // One pass over LDS with every read in flight at once (a rolled loop paid the LDS latency 2 x 19 times), and one
     // barrier: each wave reduces to (max, sum of exp relative to ITS max), the four pairs are combined by everyone.
@@ -973,6 +1013,7 @@ __device__ __forceinline__ void tower_body(const TowerArgs& A, const int pos, co
     if (stampv.on)
         for (int k = 0; k < 40; k++) A.dbg[(size_t)pos * 64 * C + wave * 40 + k] = (float)stampv.t[k];
 #endif
+    return true;
 }
 
 #ifndef SC_T32_OCC
@@ -981,7 +1022,8 @@ __device__ __forceinline__ void tower_body(const TowerArgs& A, const int pos, co
 template <class P, int C, int RS, int TPI, int AB = SC_T32_AB>
 __global__ __launch_bounds__(256, SC_T32_OCC) void k_tower32(TowerArgs A) {
     if ((int)blockIdx.x >= A.n_pos) return;
-    tower_body<P, C, RS, TPI, AB>(A, (int)blockIdx.x, nullptr);
+    NoHand nh;
+    tower_body<P, C, RS, TPI, AB>(A, (int)blockIdx.x, nullptr, NoPre(), nh);
 }
 
 }  // namespace scnn

@@ -30,6 +30,11 @@ struct TowerArgs {
     float* prior;               // [n][224] or null
     float* logp;                // [n][4672] or null
     bf16_t* hval;               // [n][16384] value-head features in the tower's accumulator order (input of k_value_fc1; weights.hpp packs the FC rows to match)
+    uint32_t* fc1_arrive;       // fused step kernel with value_head.ffn.0 inside the launch (step_kernels.hip): arrival counters, one per
+                                // 64-position block (32 words apart), monotonic: +1 per workgroup and launch; else null
+    uint32_t fc1_target;        // ... the count that says "every workgroup of the block has published its feature row in THIS launch"
+    float* vpart;               // ... the split-K partials [64][n][128] that launch writes
+    int fc1_acquire;            // ... 1: agent-scope acquire behind the poll as well (more than one workgroup per CU)
     float* dbg;                 // optional: [n][64][C] residual stream dump
     int dbg_stage;              // -1: none; 0: after stem; b>=1: after block b; 1000: final latent
 };

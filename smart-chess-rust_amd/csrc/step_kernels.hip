@@ -23,6 +23,71 @@
 
 namespace scstep {
 
+// value_head.ffn.0 inside the step launch (A.fc1_arrive != null; the engine chooses it when the slots fill whole 64-position
+// blocks and every workgroup of the launch is resident).  The layer is the network's only cross-position GEMM: tile
+// (block of 64 positions, K chunk of 256) needs the feature rows of 64 workgroups.  Each workgroup publishes its row right
+// behind the value conv (write-through stores, then one arrival per workgroup on its block's counter: tower_body), runs the
+// policy head, and then computes tile (its block, K chunk = its index in the block): weights requested first, one lane polls
+// the counter, the rows come in past the L1 (sc1 loads: hand-off form "row 1" of MI355X_MICROARCH.md; with two workgroups per
+// CU, which that table does not cover, an agent-scope acquire as well).  The partials go to the same array k_value_fc1
+// writes, for the next launch's value tail: bit-identical (same tile code, nn_kernels.hpp).  What it saves is a kernel
+// whose 9 us are mostly its cold start.  No workgroup waits for a later block, and workgroups start in index order, so the
+// wait ends even when not every workgroup is resident; it is bounded all the same (ERR_HANDOFF_TIMEOUT, ~0.2 s).
+__device__ __forceinline__ void fc1_tail(const scnn::TowerArgs& A, const sc::SpParams& p, const int g, const bool ran, scnn::Fc1Hand& fh) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int mb = g >> 6, ks = g & 63;
+    uint32_t* ctr = A.fc1_arrive + mb * 32;
+#ifdef SC_EXP   // experiment builds: stamps of the tail's phases (100 MHz), read by tools/dbg_tail.py
+#define TSTAMP(k) do { if (p.dbg_cycles && tid == 0) p.dbg_cycles[(size_t)g * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define TSTAMP(k)
+#endif
+    TSTAMP(0);
+    // a workgroup whose leaf needed no network has nothing to publish (its row keeps the last evaluation's features; the
+    // partials computed from it are never read), but the others count on its arrival
+    // (a workgroup that ran the network requested the tile's weights and a first reading of the counter under its softmax)
+    if (!ran) {
+        if (tid == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        scnn::fc1_wload(fh.w, A.net, ks, 64, wave, lane);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    const scnn::Fc1W& w = fh.w;
+    const bool have_a = ran && fh.have_a;   // (uniform over the workgroup)
+#ifdef SC_EXP
+    if (p.dbg_cycles && tid == 0) p.dbg_cycles[(size_t)g * 8 + 6] = have_a;
+    if (have_a) { TSTAMP(1); TSTAMP(2); }
+#endif
+    if (tid == 0 && !have_a) {
+        const uint64_t t0 = __builtin_amdgcn_s_memrealtime();   // 100 MHz
+        uint32_t seen = ran ? fh.early : __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        while ((int32_t)(seen - A.fc1_target) < 0) {
+            __builtin_amdgcn_s_sleep(4);
+            if (__builtin_amdgcn_s_memrealtime() - t0 > 20000000ull) {
+                atomicOr(&p.cnt->err, sc::ERR_HANDOFF_TIMEOUT);
+                break;
+            }
+            seen = __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        TSTAMP(1);
+        if (A.fc1_acquire) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        TSTAMP(2);
+    }
+    __syncthreads();   // the poll has matched (and the tower's last LDS reads are done: the tile is staged over its image)
+    scnn::bf16_t* s_a = reinterpret_cast<scnn::bf16_t*>(scnn::g_smem);
+    if (!have_a) scnn::fc1_load_a(fh.a, A.hval, mb, ks, tid);
+    scnn::fc1_put_a(s_a, fh.a, tid);
+    __syncthreads();
+    TSTAMP(3);
+    scnn::fc1_mma_store(w, s_a, A.vpart, A.n_pos, mb, ks, 64, wave, lane);
+    TSTAMP(4);
+#ifdef SC_EXP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    TSTAMP(5);
+#endif
+}
+
 template <class P, int C, int RS, int TPI, int AB>
 __global__ __launch_bounds__(256, 1) void k_step(scnn::TowerArgs A, sc::SpParams p, int do_expand) {
     __shared__ __attribute__((aligned(16))) int8_t s_stage[7168];
@@ -50,7 +115,9 @@ __global__ __launch_bounds__(256, 1) void k_step(scnn::TowerArgs A, sc::SpParams
         }
         return sc::dev_select<false>(p, g, lane, s_stage, s_moves, &s_pos, s_ps, s_hist, cs_pre, cs_pre_valid, &s_box);
     };
-    scnn::tower_body<P, C, RS, TPI, AB>(A, g, s_stage, search);
+    scnn::Fc1Hand fh;
+    const bool ran = scnn::tower_body<P, C, RS, TPI, AB>(A, g, s_stage, search, fh);
+    if (A.fc1_arrive) fc1_tail(A, p, g, ran, fh);
 }
 
 }  // namespace scstep

@@ -442,24 +442,60 @@ def test_bench_runs_under_the_launcher_with_rccl(tmp_path):
     assert line["n_gpus"] == 1 and line["value"] > 1e5 and line["error_flags"] == 0 and line["roofline"]["frac"] > 0.1
 
 
-@pytest.mark.parametrize("C,precision", [(128, "bf16"), (256, "bf16"), (128, "fp8")])
-def test_fused_step_kernel_equals_the_two_launch_form(scamd, C, precision):
+@pytest.mark.parametrize("C,precision,n_slots", [(128, "bf16", 24), (256, "bf16", 24), (128, "fp8", 24),
+                                                 (128, "bf16", 64), (256, "bf16", 128), (128, "fp8", 192), (128, "bf16", 256), (128, "fp8", 512)])
+def test_fused_step_kernel_equals_the_two_launch_form(scamd, C, precision, n_slots):
     """the fused simulation step (search wave = wave 0 of the tower workgroup, planes handed over in LDS) plays bit-identical
     games to k_mcts + k_tower32 as separate launches (which a handle uses while every launch is timed): moves, visit
-    counts, value sums and uct words of every ply, with root noise, temperature sampling and slot recycling"""
+    counts, value sums and uct words of every ply, with root noise, temperature sampling and slot recycling.  With whole
+    64-slot blocks the step is ONE launch: value_head.ffn.0's tiles are computed by the step kernel's workgroups from feature
+    rows handed over inside the launch (uneven load: games end, leaves are terminal, slots idle at the end) -- every partial
+    sum feeds a value, every value a backup, so a single stale word shows up in the traces."""
     eng = scamd.Engine(3, C, seed=4, precision=precision)
-    cfg = dict(n_slots=24, n_games=40, rollout_num=20, num_steps=9, cpuct=2.5, temperature=0.5, temperature_switch=3, with_noise=True, seed=12,
-               outcome_gate=0)
+    n_games = n_slots + n_slots // 2 + 4
+    cfg = dict(n_slots=n_slots, n_games=n_games, rollout_num=20, num_steps=9, cpuct=2.5, temperature=0.5, temperature_switch=3, with_noise=True,
+               seed=12, outcome_gate=0)
     a = scamd.SelfPlay(eng, **cfg)
     a.run()
     b = scamd.SelfPlay(eng, **cfg)
     b.enable_timing(1)                       # every tower launch bracketed by events: the two-launch form
     b.run()
     assert b.timing(reset=False)["tower_launches"] > 100
-    for g in range(40):
+    for g in range(n_games):
         ta, tb = a.trace(g), b.trace(g)
         assert ta is not None and ta == tb, g
-    assert a.stats() == b.stats() and a.stats()["error_flags"] == 0 and a.stats()["games_finished"] == 40
+    assert a.stats() == b.stats() and a.stats()["error_flags"] == 0 and a.stats()["games_finished"] == n_games
     for h in (a, b):
         h.close()
     eng.close()
+
+
+@pytest.mark.parametrize("where", ["trunk", "policy", "value"])
+def test_non_finite_parameters_stay_visible_per_head(scamd, tmp_path, where):
+    """a NaN in the network is not swallowed by a ReLU (hardware max maps NaN to 0; the reference warns on non-finite values,
+    src/backends/torch.rs:129-135): in the trunk it reaches both outputs, in one head only that head's output -- the heads
+    are separate branches (py/module.py:136-152), the other output equals the clean network's bit for bit"""
+    import scw
+    sd = scw.prng_state_dict(2, 128, 7)
+    clean = str(tmp_path / "clean.scw")
+    scw.write_scw(clean, sd, 2, 128)
+    key = {"trunk": "res_blocks.0.conv1.bias", "policy": "policy_head.model.0.bias", "value": "value_head.conv.0.bias"}[where]
+    sd[key] = sd[key].copy()
+    sd[key][3] = np.nan
+    bad = str(tmp_path / "bad.scw")
+    scw.write_scw(bad, sd, 2, 128)
+    g = np.load(os.path.join(GOLD, "nn_ref_b1_c256.npz"))
+    a, b = scamd.Engine(weights=clean), scamd.Engine(weights=bad)
+    la, va = a.forward(g["boards"][:3], g["meta"][:3])
+    lb, vb = b.forward(g["boards"][:3], g["meta"][:3])
+    assert np.isfinite(la).all() and np.isfinite(va).all()
+    if where in ("trunk", "policy"):
+        assert np.isnan(lb).all()
+    else:
+        assert np.array_equal(la, lb)
+    if where in ("trunk", "value"):
+        assert np.isnan(vb).all()
+    else:
+        assert np.array_equal(va, vb)
+    a.close()
+    b.close()
