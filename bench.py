@@ -23,7 +23,7 @@ import sys
 import time
 
 # Kernel arguments in device memory instead of host-coherent memory: every launch otherwise starts with a PCIe round trip
-# for its argument block (three launches per simulation step: +6 % simulations/s measured).  Must be set before the HIP
+# for its argument block (+6 % simulations/s measured in round 1, with three launches per simulation step).  Must be set before the HIP
 # runtime initialises, i.e. before torch / the engine library are loaded.
 os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
 
@@ -270,7 +270,7 @@ def main():
     ap.add_argument("--groups", type=int, default=1, help="split the games of a GPU into K groups on K HIP streams (overlap)")
     ap.add_argument("--timing-stride", type=int, default=32,
                     help="every n-th simulation step runs as separate launches with the tower bracketed by a HIP event pair for the "
-                         "roofline figure (the other steps use the fused step kernel; a timed step is ~5 us slower)")
+                         "roofline figure (the other steps are ONE launch, the fused step kernel; a timed step is ~8 us slower)")
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU work for cpu_baseline (0 = skip)")
     ap.add_argument("--cpu-dry-run", action="store_true",
                     help="HARNESS TEST ONLY (gloo, no GPU): exercises sharding/timing/aggregation with the oracle's "
@@ -384,7 +384,8 @@ def main():
                 "frac": round(tf / peak, 4), "traffic": load_traffic(m["C"], m.get("precision", "bf16")),
                 "kernel": f"k_tower32<{m.get('precision', 'bf16')}, {m['C']}>", "avg_launch_ms": round(m["tower_ms"], 4), "launches_timed": m["tower_launches"],
                 "flop_per_launch": pos_per_launch * flop_tower, "positions_per_launch": pos_per_launch, "concurrent_groups": m.get("groups", 1),
-                "flop_note": "the tower launch's own layers (stem, blocks, head convs); value_head.ffn runs in k_value_fc1 / the search kernel",
+                "flop_note": "the tower launch's own layers (stem, blocks, head convs) on the timed (separately launched) steps; value_head.ffn "
+                             "runs in k_value_fc1 / the search kernel there, inside the fused step kernel on the other steps",
                 "end_to_end_frac": round(sims / seconds / world * flop_pos / (peak * 1e12), 4),
             }
             out["nn_evals_per_sim"] = round(m["nn_evals"] / max(m["sims_all"], 1), 4)

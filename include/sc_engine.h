@@ -251,7 +251,8 @@ int sc_search(sc_engine*, const uint16_t* moves, int n_moves, int rollout, float
  * caller-provided finite values: out[0] = the one-round form used for nodes with <= 64 children (-2 if n > 64),
  * out[1] = the four-round (value, index) form used for wider nodes. */
 int sc_debug_find_max(int device_id, const float* values, int n, int32_t* out2);
-/* developer aid: cycle stamps of the last search-kernel launch, out[n_slots][8] (tools/dbg_cycles.py) */
+/* developer aid: stamps of the last launch, out[n_slots][16]: 0..7 the search's cycle stamps (tools/dbg_cycles.py), 8..15
+ * written by experiment builds only (tools/dbg_tail.py) */
 int sc_selfplay_debug_cycles(sc_selfplay*, int enable, unsigned long long* out);
 
 /* utility: trace-file JSON writer on caller-provided arrays (no GPU needed) */

@@ -1245,13 +1245,13 @@ int sc_selfplay_debug_cycles(sc_selfplay* sp, int enable, unsigned long long* ou
     HIPOK(hipSetDevice(sp->device));
     HIPOK(hipStreamSynchronize(sp->stream));
     if (enable && !sp->p.dbg_cycles) {
-        HIPOK(dalloc(&sp->p.dbg_cycles, (size_t)sp->p.n_slots * 8));
+        HIPOK(dalloc(&sp->p.dbg_cycles, (size_t)sp->p.n_slots * 16));
         sp->allocs.push_back(sp->p.dbg_cycles);
-        HIPOK(hipMemset(sp->p.dbg_cycles, 0, (size_t)sp->p.n_slots * 64));
+        HIPOK(hipMemset(sp->p.dbg_cycles, 0, (size_t)sp->p.n_slots * 128));
         HIPOK(hipDeviceSynchronize());
     }
     if (out && sp->p.dbg_cycles)
-        HIPOK(hipMemcpy(out, sp->p.dbg_cycles, (size_t)sp->p.n_slots * 64, hipMemcpyDeviceToHost));
+        HIPOK(hipMemcpy(out, sp->p.dbg_cycles, (size_t)sp->p.n_slots * 128, hipMemcpyDeviceToHost));
     return 0;
 }
 

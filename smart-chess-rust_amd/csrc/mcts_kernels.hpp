@@ -309,7 +309,7 @@ constexpr int DEPTH_LDS = 1024;  // path entries tracked in LDS (a deeper path s
 
 #define SC_STAMP(k)                                                                   \
     do {                                                                              \
-        if (p.dbg_cycles && lane == 0) p.dbg_cycles[(size_t)g * 8 + (k)] = clock64(); \
+        if (p.dbg_cycles && lane == 0) p.dbg_cycles[(size_t)g * 16 + (k)] = clock64(); \
     } while (0)
 
 // Hand-off to a helper wavefront (fused step kernel): once the leaf position and its repetition flags stand, the plane
@@ -528,7 +528,7 @@ __device__ __forceinline__ bool dev_select(const SpParams& p, int g, int lane, i
         }
     }
     SC_STAMP(3);
-    if (p.dbg_cycles && lane == 0) p.dbg_cycles[(size_t)g * 8 + 7] = depth;   // developer stamp: levels walked
+    if (p.dbg_cycles && lane == 0) p.dbg_cycles[(size_t)g * 16 + 7] = depth;   // developer stamp: levels walked
     unsigned long long anyerr = __ballot(err != 0);
     if (anyerr) {
         for (int o = 32; o > 0; o >>= 1) err |= __shfl_xor(err, o, 64);

@@ -39,7 +39,7 @@ __device__ __forceinline__ void fc1_tail(const scnn::TowerArgs& A, const sc::SpP
     const int mb = g >> 6, ks = g & 63;
     uint32_t* ctr = A.fc1_arrive + mb * 32;
 #ifdef SC_EXP   // experiment builds: stamps of the tail's phases (100 MHz), read by tools/dbg_tail.py
-#define TSTAMP(k) do { if (p.dbg_cycles && tid == 0) p.dbg_cycles[(size_t)g * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define TSTAMP(k) do { if (p.dbg_cycles && tid == 0) p.dbg_cycles[(size_t)g * 16 + 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define TSTAMP(k)
 #endif
@@ -55,7 +55,7 @@ __device__ __forceinline__ void fc1_tail(const scnn::TowerArgs& A, const sc::SpP
     const scnn::Fc1W& w = fh.w;
     const bool have_a = ran && fh.have_a;   // (uniform over the workgroup)
 #ifdef SC_EXP
-    if (p.dbg_cycles && tid == 0) p.dbg_cycles[(size_t)g * 8 + 6] = have_a;
+    if (p.dbg_cycles && tid == 0) p.dbg_cycles[(size_t)g * 16 + 14] = have_a;
     if (have_a) { TSTAMP(1); TSTAMP(2); }
 #endif
     if (tid == 0 && !have_a) {
@@ -107,12 +107,14 @@ __global__ __launch_bounds__(256, 1) void k_step(scnn::TowerArgs A, sc::SpParams
             sc::dev_encode_helper(p, g, lane, &s_box, s_stage, &s_pos, s_ps, s_hist);
             return true;
         }
+        SC_STAMP(0);
         sc::GameCtl cs_pre{};
         bool cs_pre_valid = false;
         if (do_expand) {
             sc::dev_expand(p, g, lane, &s_pos, cs_pre, cs_pre_valid);
             __builtin_amdgcn_wave_barrier();
         }
+        SC_STAMP(1);
         return sc::dev_select<false>(p, g, lane, s_stage, s_moves, &s_pos, s_ps, s_hist, cs_pre, cs_pre_valid, &s_box);
     };
     scnn::Fc1Hand fh;

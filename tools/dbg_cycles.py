@@ -15,7 +15,7 @@ acc = []
 for it in range(20):
     sp.enqueue(3)
     eng.L.sc_engine_synchronize(eng.h)   # plain stream sync: no flush launch, stamps are from the last full k_mcts
-    out = np.zeros((G, 8), np.uint64)
+    out = np.zeros((G, 16), np.uint64)
     L.sc_selfplay_debug_cycles(sp.h, 0, out.ctypes.data)
     acc.append(out.astype(np.int64))
 a = np.stack(acc)  # [it][G][8]
@@ -23,6 +23,9 @@ names = ["expand (0->1)", "ctl+descent (2->3)", "leafpos+rep (3->4)", "stage+mov
 d = [a[..., 1] - a[..., 0], a[..., 3] - a[..., 2], a[..., 4] - a[..., 3], a[..., 5] - a[..., 4], a[..., 6] - a[..., 5], a[..., 6] - a[..., 0]]
 for n, x in zip(names, d):
     x = x[(x > 0) & (x < 10**7)]
+    if x.size == 0:
+        print(f"{n:24s} (no stamps)")
+        continue
     print(f"{n:24s} median {np.median(x):9.0f}  mean {x.mean():9.0f}  p90 {np.percentile(x, 90):9.0f}  max {x.max():9.0f}  (s_memtime ticks)")
 dep = a[..., 7].astype(np.float64)
 des = (a[..., 3] - a[..., 2]).astype(np.float64)

@@ -17,13 +17,13 @@ acc = []
 for it in range(20):
     sp.enqueue(3)
     eng.L.sc_engine_synchronize(eng.h)
-    out = np.zeros((G, 8), np.uint64)
+    out = np.zeros((G, 16), np.uint64)
     L.sc_selfplay_debug_cycles(sp.h, 0, out.ctypes.data)
     acc.append(out.astype(np.int64))
 a = np.stack(acc)
-for n, i, j in [("entry->poll matched", 0, 1), ("acquire+drain", 1, 2), ("stage A", 2, 3), ("mma+store issue", 3, 4), ("store drain", 4, 5), ("whole tail", 0, 5)]:
+for n, i, j in [("entry->poll matched", 8, 9), ("acquire+drain", 9, 10), ("stage A", 10, 11), ("mma+store issue", 11, 12), ("store drain", 12, 13), ("whole tail", 8, 13)]:
     x = (a[..., j] - a[..., i]) * 10.0
     print(f"{n:24s} median {np.median(x):8.0f} ns  mean {x.mean():8.0f}  p90 {np.percentile(x, 90):8.0f}  max {x.max():8.0f}")
-print("early A loads: fraction of workgroups", a[..., 6].mean())
-t0 = a[..., 0]; print("entry spread over the grid (max-min per launch, ns):", np.median((t0.max(1) - t0.min(1)) * 10.0))
-t5 = a[..., 5]; print("exit spread:", np.median((t5.max(1) - t5.min(1)) * 10.0), " last exit - last entry:", np.median((t5.max(1) - t0.max(1)) * 10.0))
+print("early A loads: fraction of workgroups", a[..., 14].mean())
+t0 = a[..., 8]; print("entry spread over the grid (max-min per launch, ns):", np.median((t0.max(1) - t0.min(1)) * 10.0))
+t5 = a[..., 13]; print("exit spread:", np.median((t5.max(1) - t5.min(1)) * 10.0), " last exit - last entry:", np.median((t5.max(1) - t0.max(1)) * 10.0))
