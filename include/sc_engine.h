@@ -200,6 +200,12 @@ int sc_selfplay_enable_timing(sc_selfplay*, int stride);
  * Reference settings: with_noise = 0, outcome_gate = -1 (outcome after every ply), num_steps = 200, tie_random = 1. */
 int sc_selfplay_set_players(sc_selfplay*, sc_engine* white, sc_engine* black, uint64_t synth_salt_white, uint64_t synth_salt_black);
 int sc_selfplay_timing(sc_selfplay*, int reset, float* ms_total, float* ms_nn, int64_t* nn_launches);
+/* Kernel launches per simulation step this handle uses with SC_EVAL_NET (steps bracketed for sc_selfplay_timing always use 3):
+ * 1 = the fused step kernel with value_head.ffn.0 inside (whole 64-slot blocks, every workgroup resident, and no other
+ *     stream of this process running that form on the device: its workgroups wait for each other inside the launch),
+ * 2 = the fused step kernel + the value FC launch, 3 = search, network tower and value FC as separate launches.
+ * All three play bit-identical games.  0 for handles without a network. */
+int sc_selfplay_launches_per_step(const sc_selfplay*);
 
 /* Trace of a finished game = the reference's Trace<M,O> (src/trace.rs:5-9) in SoA form.
  * Call with NULL arrays to query sizes first.  child_off has n_steps+1 entries. */

@@ -11,6 +11,8 @@
 #include <string.h>
 
 #include <algorithm>
+#include <map>
+#include <mutex>
 #include <string>
 #include <utility>
 #include <initializer_list>
@@ -497,6 +499,31 @@ int sc_encode_steps(sc_engine* e, int device_id, int n_games, const uint16_t* mo
 // ============================================================================================
 // self-play
 // ============================================================================================
+// Step launches that compute value_head.ffn.0 inside the launch (sp->fc1_in_step) make workgroups wait for other workgroups
+// of the same launch.  Two such launches running side by side on one device (two streams) could each hold compute units the
+// other's late workgroups need: on one device the form is therefore granted to the handles of ONE stream at a time (the first
+// to ask; an engine's handles share its stream and run one after the other); any other handle uses the two-launch form.
+// (Two PROCESSES sharing a GPU are not covered: the waits are bounded -- error flag 32 -- but one self-play process per GPU
+// is the deployment this library is written for.)
+static std::mutex g_fc1_mu;
+static std::map<int, std::pair<hipStream_t, int>> g_fc1_stream;   // device -> (stream, live handles)
+static bool fc1_stream_acquire(int device, hipStream_t s) {
+    std::lock_guard<std::mutex> lk(g_fc1_mu);
+    auto it = g_fc1_stream.find(device);
+    if (it == g_fc1_stream.end() || it->second.second == 0) {
+        g_fc1_stream[device] = {s, 1};
+        return true;
+    }
+    if (it->second.first != s) return false;
+    it->second.second++;
+    return true;
+}
+static void fc1_stream_release(int device) {
+    std::lock_guard<std::mutex> lk(g_fc1_mu);
+    auto it = g_fc1_stream.find(device);
+    if (it != g_fc1_stream.end() && it->second.second > 0) it->second.second--;
+}
+
 struct sc_selfplay {
     sc_engine* engine = nullptr;
     int device = 0;
@@ -698,6 +725,7 @@ int sc_selfplay_create(sc_engine* e, int device_id, const sc_selfplay_config* cf
 #ifdef SC_FC1_IN_STEP_OFF   // A/B builds
     sp->fc1_in_step = false;
 #endif
+    if (sp->fc1_in_step) sp->fc1_in_step = fc1_stream_acquire(sp->device, sp->stream);
     // the zero-fills above ran on the NULL stream, which does not order against the (non-blocking) launch
     // stream: make them complete before the first kernel touches the buffers
     hipError_t he = hipDeviceSynchronize();
@@ -714,6 +742,7 @@ void sc_selfplay_destroy(sc_selfplay* sp) {
     (void)hipSetDevice(sp->device);
     if (sp->stream) (void)hipStreamSynchronize(sp->stream);
     else (void)hipDeviceSynchronize();
+    if (sp->fc1_in_step) fc1_stream_release(sp->device);
     for (void* a : sp->allocs) (void)hipFree(a);
     for (hipEvent_t ev : sp->ev) (void)hipEventDestroy(ev);
     if (sp->ev_begin) (void)hipEventDestroy(sp->ev_begin);
@@ -924,6 +953,11 @@ int sc_selfplay_run(sc_selfplay* sp, int64_t max_sim_steps) {
         if (st.games_active == 0) break;
     }
     return 0;
+}
+
+int sc_selfplay_launches_per_step(const sc_selfplay* sp) {
+    if (!sp || sp->p.evaluator != SC_EVAL_NET) return 0;
+    return sp->fc1_in_step ? 1 : sp->fused ? 2 : 3;
 }
 
 int sc_selfplay_timing(sc_selfplay* sp, int reset, float* ms_total, float* ms_nn, int64_t* nn_launches) {

@@ -78,6 +78,7 @@ ABI = {
     "sc_selfplay_set_players": (_i, [_vp, _vp, _vp, C.c_uint64, C.c_uint64]),
     "sc_selfplay_enable_timing": (_i, [_vp, _i]),
     "sc_selfplay_timing": (_i, [_vp, _i, C.POINTER(_f), C.POINTER(_f), C.POINTER(_i64)]),
+    "sc_selfplay_launches_per_step": (_i, [_vp]),
     "sc_selfplay_get_trace": (_i, [_vp, _i, C.POINTER(TraceInfo), _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sc_selfplay_write_trace_json": (_i, [_vp, _i, C.c_char_p]),
     "sc_selfplay_get_tree": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -500,6 +501,10 @@ class SelfPlay:
 
     def enable_timing(self, stride=1):
         _check(self.L.sc_selfplay_enable_timing(self.h, stride))
+
+    def launches_per_step(self):
+        """1: fused step kernel with the value FC inside, 2: fused step kernel + value FC launch, 3: separate launches"""
+        return int(self.L.sc_selfplay_launches_per_step(self.h))
 
     def timing(self, reset=True):
         a, b, n = C.c_float(0), C.c_float(0), C.c_int64(0)

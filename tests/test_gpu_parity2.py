@@ -499,3 +499,32 @@ def test_non_finite_parameters_stay_visible_per_head(scamd, tmp_path, where):
         assert np.array_equal(va, vb)
     a.close()
     b.close()
+
+
+def test_one_launch_form_is_granted_to_one_stream_per_device(scamd):
+    """the one-launch step makes workgroups wait for workgroups of the same launch, so two such launches must not run side by
+    side on one device: handles of a second engine (its own stream) get the two-launch form while a handle of the first is
+    alive, ragged slot counts get it always -- and all of them play the same games"""
+    e1, e2 = scamd.Engine(2, 128, seed=9), scamd.Engine(2, 128, seed=9)
+    cfg = dict(n_games=80, rollout_num=16, num_steps=8, cpuct=2.5, with_noise=True, seed=3, outcome_gate=0)
+    a = scamd.SelfPlay(e1, n_slots=64, **cfg)
+    b = scamd.SelfPlay(e2, n_slots=64, **cfg)
+    c = scamd.SelfPlay(e1, n_slots=64, **cfg)
+    d = scamd.SelfPlay(e1, n_slots=40, **cfg)
+    assert [h.launches_per_step() for h in (a, b, c, d)] == [1, 2, 1, 2]
+    for _ in range(40):                      # interleaved: the two engines' streams run side by side
+        for h in (a, b):
+            h.enqueue(8)
+    for h in (a, b, c, d):
+        h.run()
+    for g in range(80):
+        t = a.trace(g)
+        assert t is not None and t == b.trace(g) == c.trace(g) == d.trace(g), g
+    for h in (a, b, c, d):
+        assert h.stats()["error_flags"] == 0 and h.stats()["games_finished"] == 80
+    a.close(); c.close()
+    f = scamd.SelfPlay(e2, n_slots=64, **cfg)     # the first stream's handles are gone: the form is free again
+    assert f.launches_per_step() == 1
+    for h in (b, d, f):
+        h.close()
+    e1.close(); e2.close()
