@@ -315,7 +315,8 @@ constexpr int DEPTH_LDS = 1024;  // path entries tracked in LDS (a deeper path s
 // Hand-off to a helper wavefront (fused step kernel): once the leaf position and its repetition flags stand, the plane
 // encoding (history loads + 7 KB of LDS writes) is independent of move generation; wave 1 of the workgroup, idle during
 // the search, does it while this wave generates the moves.  An LDS mailbox: the searching wave writes idx / root_ply,
-// then state (1 = encode, 2 = nothing to do); the helper polls state.
+// then state (1 = encode, 2 = nothing to do, 3 = the leaf's repetition flags first -- answered with state 4 and the flags in
+// `pad` --, then encode); the helper polls state.
 struct HelperBox {
     int state, idx, root_ply, pad;
 };
@@ -338,10 +339,24 @@ __device__ __forceinline__ void dev_encode_helper(const SpParams& p, int g, int 
     }
     st = __builtin_amdgcn_readfirstlane(st);
     if (st == 0 && lane == 0) atomicOr(&p.cnt->err, ERR_HELPER_TIMEOUT);   // never seen: the search wave posts on every path
-    if (st != 1) return;
+    if (st != 1 && st != 3) return;
     wave_sync();
     const int idx = __builtin_amdgcn_readfirstlane(box->idx), root_ply = __builtin_amdgcn_readfirstlane(box->root_ply);
     DevChain ch{p.hist + (size_t)g * p.hist_cap, root_ply, p.tpos + (size_t)g * p.tpos_cap, s_ps, s_leaf_p, idx};
+    if (st == 3) {
+        // the leaf's repetition flags (move generation does not need them: the search wave is already generating the moves
+        // and collects the flags from the mailbox afterwards)
+        const bb_t key0 = s_leaf_p->key;
+        const uint8_t rf = (uint8_t)__builtin_amdgcn_readfirstlane((int)rep_flags_wave(ch, idx, key0, lane));
+        const uint8_t fl = (uint8_t)((s_leaf_p->flags & F_IRREV) | rf);
+        wave_sync();   // every lane has read the old flags
+        if (lane == 0) {
+            s_leaf_p->flags = fl;
+            box->pad = fl;
+        }
+        wave_sync();
+        if (lane == 0) *reinterpret_cast<volatile int*>(&box->state) = 4;
+    }
     stage_history(ch, idx, lane, s_hist);
     wave_sync();
     encode_wave(s_hist, idx < 7 ? idx + 1 : 8, lane, s_stage, nullptr, p.meta + (size_t)g * 8);
@@ -562,7 +577,8 @@ __device__ __forceinline__ bool dev_select(const SpParams& p, int g, int lane, i
     if (lane == 0) s_leaf = pos;
     wave_sync();  // s_leaf, s_ps visible
     DevChain ch{hist, root_ply, tpos, s_ps, &s_leaf, root_ply + depth};
-    if (depth > 0) {
+    const bool rep_by_helper = box && depth > 0;   // the helper wave scans for repetitions too (a round trip off this wave's chain)
+    if (depth > 0 && !box) {
         uint8_t rf = (uint8_t)__builtin_amdgcn_readfirstlane((int)rep_flags_wave(ch, root_ply + depth, pos.key, lane));
         pos.flags = (uint8_t)((pos.flags & F_IRREV) | rf);
         wave_sync();
@@ -572,10 +588,10 @@ __device__ __forceinline__ bool dev_select(const SpParams& p, int g, int lane, i
     SC_STAMP(4);
     // history for the encoder: issued now so the loads overlap move generation -- or the whole encoding handed to the
     // helper wave (a terminal leaf wastes its work: nothing reads the planes then)
-    if (box) helper_post(box, lane, 1, root_ply + depth, root_ply);
+    if (box) helper_post(box, lane, rep_by_helper ? 3 : 1, root_ply + depth, root_ply);
     else stage_history(ch, root_ply + depth, lane, s_hist);
-    // scratch slot for the expansion (claimed in dev_expand if the leaf is not terminal)
-    if (lane == 0) tpos[cs.n_exp] = pos;
+    // scratch slot for the expansion (claimed in dev_expand if the leaf is not terminal); with the helper's flags: below
+    if (lane == 0 && !rep_by_helper) tpos[cs.n_exp] = pos;
     int n = 0;
     bool in_check = gen_legal_wave(pos, s_moves, lane, n);   // lane = square (chess_rules_wave.hpp)
     wave_sync();
@@ -611,6 +627,18 @@ __device__ __forceinline__ bool dev_select(const SpParams& p, int g, int lane, i
     if (__ballot(bad) && lane == 0) {
         c.err = cs.err | err | ERR_BAD_MOVE_INDEX;
         atomicOr(&p.cnt->err, ERR_BAD_MOVE_INDEX);
+    }
+    if (rep_by_helper) {
+        int st = 3;
+        for (int spin = 0; spin < (1 << 22) && st != 4; spin++) {   // (long answered: the scan is shorter than move generation)
+            st = *reinterpret_cast<volatile int*>(&box->state);
+            if (st != 4) __builtin_amdgcn_s_sleep(1);
+        }
+        st = __builtin_amdgcn_readfirstlane(st);
+        wave_sync();
+        if (st != 4 && lane == 0) atomicOr(&p.cnt->err, ERR_HELPER_TIMEOUT);
+        pos.flags = (uint8_t)__builtin_amdgcn_readfirstlane(box->pad);
+        if (lane == 0) tpos[cs.n_exp] = pos;
     }
     const int idx = root_ply + depth;
     if (!box) encode_wave(s_hist, idx < 7 ? idx + 1 : 8, lane, s_stage, PLANES_TO_HBM ? p.boards + (size_t)g * 7168 : nullptr, p.meta + (size_t)g * 8);
