@@ -151,8 +151,6 @@ __device__ __forceinline__ void fc1_wload(Fc1W& w, const NetDev& net, int ks, in
 // The 64 feature rows of the tile are the same for all four waves (each owns 32 of the 128 output columns): they go
 // through LDS once -- [row][kchunk + 8] bf16, the 16-byte pad keeps the 16 rows of a fragment read on distinct banks --
 // instead of four times through the CU's 64 B/clk vector-memory path (two thirds of the tile's operand traffic).
-// SC1: the rows were published by other workgroups of the SAME launch (write-through stores): load them past this CU's L1.
-template <bool SC1>
 __device__ __forceinline__ void fc1_stage_a(bf16_t* s_a, const bf16_t* hval, int n_pos, int mb, int ks, int ksplit, int tid) {
     typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
     const int kchunk = FC1_K / ksplit;  // multiple of 32
@@ -164,12 +162,12 @@ __device__ __forceinline__ void fc1_stage_a(bf16_t* s_a, const bf16_t* hval, int
     for (int c = tid; c < pieces; c += 256) {
         const int r = c / (kchunk / 8), q = c % (kchunk / 8);
         const int row = r < last ? r : last;
-        const int off = (row * FC1_K + ks * kchunk + q * 8) * 2;
-        const u32x4 v = SC1 ? __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, AUX_SC1) : __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
-        *reinterpret_cast<u32x4*>(s_a + r * apitch + q * 8) = v;
+        *reinterpret_cast<u32x4*>(s_a + r * apitch + q * 8) =
+            __builtin_amdgcn_raw_buffer_load_b128(rsrc, (row * FC1_K + ks * kchunk + q * 8) * 2, 0, 0);
     }
 }
-// the same in two halves for split-K 64 and a full block of 64 rows (the fused step kernel): the loads (sc1) into registers ...
+// the same in two halves for split-K 64 and a full block of 64 rows (the fused step kernel, where the rows were published by
+// other workgroups of the SAME launch with write-through stores): sc1 loads, past this CU's L1, into registers ...
 __device__ __forceinline__ void fc1_load_a(__attribute__((ext_vector_type(4))) unsigned int (&a)[8], const bf16_t* hval, int mb, int ks, int tid) {
     const __amdgpu_buffer_rsrc_t rsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(hval) + (size_t)mb * 64 * FC1_K, 0, 0x7fffffff, 0x00020000);
@@ -227,7 +225,7 @@ __global__ __launch_bounds__(256) void k_value_fc1(Fc1Args A) {
     __shared__ __attribute__((aligned(16))) bf16_t s_a[FC1_TILE_LDS / 2];
     Fc1W w;
     fc1_wload(w, A.net, ks, A.ksplit, wave, lane);
-    fc1_stage_a<false>(s_a, A.hval, A.n_pos, mb, ks, A.ksplit, tid);
+    fc1_stage_a(s_a, A.hval, A.n_pos, mb, ks, A.ksplit, tid);
     __syncthreads();   // A tile staged
     fc1_mma_store(w, s_a, A.vpart, A.n_pos, mb, ks, A.ksplit, wave, lane);
 }

@@ -27,9 +27,10 @@ namespace scstep {
 // blocks and every workgroup of the launch is resident).  The layer is the network's only cross-position GEMM: tile
 // (block of 64 positions, K chunk of 256) needs the feature rows of 64 workgroups.  Each workgroup publishes its row right
 // behind the value conv (write-through stores, then one arrival per workgroup on its block's counter: tower_body), runs the
-// policy head, and then computes tile (its block, K chunk = its index in the block): weights requested first, one lane polls
-// the counter, the rows come in past the L1 (sc1 loads: hand-off form "row 1" of MI355X_MICROARCH.md; with two workgroups per
-// CU, which that table does not cover, an agent-scope acquire as well).  The partials go to the same array k_value_fc1
+// policy head, and then computes tile (its block, K chunk = its index in the block): one lane polls the counter, the rows come
+// in past the L1 (sc1 loads: hand-off form "row 1" of MI355X_MICROARCH.md; with two workgroups per CU, which that table does
+// not cover, an agent-scope acquire as well).  The tile's weights, a counter reading and -- where an earlier reading already
+// showed the block complete -- the rows themselves are requested by the tower under its softmax (Fc1Hand, nn_tower32.hpp).  The partials go to the same array k_value_fc1
 // writes, for the next launch's value tail: bit-identical (same tile code, nn_kernels.hpp).  What it saves is a kernel
 // whose 9 us are mostly its cold start.  No workgroup waits for a later block, and workgroups start in index order, so the
 // wait ends even when not every workgroup is resident; it is bounded all the same (ERR_HANDOFF_TIMEOUT, ~0.2 s).

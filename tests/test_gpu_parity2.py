@@ -443,7 +443,7 @@ def test_bench_runs_under_the_launcher_with_rccl(tmp_path):
 
 
 @pytest.mark.parametrize("C,precision,n_slots", [(128, "bf16", 24), (256, "bf16", 24), (128, "fp8", 24),
-                                                 (128, "bf16", 64), (256, "bf16", 128), (128, "fp8", 192), (128, "bf16", 256), (128, "fp8", 512)])
+                                                 (128, "bf16", 64), (256, "bf16", 128), (128, "fp8", 192), (256, "fp8", 64), (128, "bf16", 256), (128, "fp8", 512)])
 def test_fused_step_kernel_equals_the_two_launch_form(scamd, C, precision, n_slots):
     """the fused simulation step (search wave = wave 0 of the tower workgroup, planes handed over in LDS) plays bit-identical
     games to k_mcts + k_tower32 as separate launches (which a handle uses while every launch is timed): moves, visit
