@@ -15,11 +15,12 @@ for n in [int(x) for x in sys.argv[3:]]:
     sp.enqueue(40)
     sp.enable_timing(1)
     sp.timing(reset=True)
-    sp.enqueue(200)
+    steps = int(os.environ.get("SC_TT_STEPS", "200"))   # (long runs: power / clock sampling, tools/power_all.sh)
+    sp.enqueue(steps)
     t = sp.timing()
     ms = t["ms_tower_sum"] / max(t["tower_launches"], 1)
     flop = 2.0 * (64 * 112 * 9 * C + nb * (2 * 64 * C * 9 * C + C * C) + 2 * 64 * C * 256 + 64 * 256 * 73)
     print(f"{eng.precision} {nb}x{C} slots {n:5d}: tower {ms * 1e3:8.1f} us  {n / ms / 1e3:7.3f} M positions/s  {n * flop / ms / 1e9:7.1f} TFLOP/s  "
-          f"step {t['ms_total'] / 200 * 1e3:7.1f} us", flush=True)
+          f"step {t['ms_total'] / steps * 1e3:7.1f} us", flush=True)
     sp.close()
     eng.close()
