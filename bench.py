@@ -384,6 +384,8 @@ def main():
                 "frac": round(tf / peak, 4), "traffic": load_traffic(m["C"], m.get("precision", "bf16")),
                 "kernel": f"k_tower32<{m.get('precision', 'bf16')}, {m['C']}>", "avg_launch_ms": round(m["tower_ms"], 4), "launches_timed": m["tower_launches"],
                 "flop_per_launch": pos_per_launch * flop_tower, "positions_per_launch": pos_per_launch, "concurrent_groups": m.get("groups", 1),
+                "chip_sustains_note": "a register-resident loop of independent bf16 32x32x16 MFMAs with non-zero operands holds 1989 TFLOP/s "
+                                      "(0.80 of peak) at this pool's 1400 W cap; this run draws ~1300 W (profiles/r02_exp_power_and_clock.txt)",
                 "flop_note": "the tower launch's own layers (stem, blocks, head convs) on the timed (separately launched) steps; value_head.ffn "
                              "runs in k_value_fc1 / the search kernel there, inside the fused step kernel on the other steps",
                 "end_to_end_frac": round(sims / seconds / world * flop_pos / (peak * 1e12), 4),
