@@ -257,6 +257,11 @@ int sc_search(sc_engine*, const uint16_t* moves, int n_moves, int rollout, float
  * caller-provided finite values: out[0] = the one-round form used for nodes with <= 64 children (-2 if n > 64),
  * out[1] = the four-round (value, index) form used for wider nodes. */
 int sc_debug_find_max(int device_id, const float* values, int n, int32_t* out2);
+/* test aid: makes the NEXT one-launch steps of the handle wait for arrivals that never come (the in-launch hand-off's target is
+ * raised by `missing` arrivals per block), to show on hardware that the wait is bounded: every workgroup gives up after ~0.2 s,
+ * the launch ends and error_flags carries bit 32.  The handle's results are invalid afterwards.  No effect (returns 1) on a
+ * handle that does not use the one-launch form. */
+int sc_selfplay_debug_break_handoff(sc_selfplay*, int missing);
 /* developer aid: stamps of the last launch, out[n_slots][16]: 0..7 the search's cycle stamps (tools/dbg_cycles.py), 8..15
  * written by experiment builds only (tools/dbg_tail.py) */
 int sc_selfplay_debug_cycles(sc_selfplay*, int enable, unsigned long long* out);

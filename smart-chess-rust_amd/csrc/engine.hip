@@ -560,6 +560,7 @@ struct sc_selfplay {
     bool fc1_in_step = false;        // ... and value_head.ffn.0 runs inside that launch too (one launch per simulation step)
     uint32_t* d_fc1_ctr = nullptr;   // its arrival counters, one per 64-position block, 128 B apart (monotonic)
     uint32_t fc1_launches = 0;       // step launches that counted on them so far
+    uint32_t fc1_target_skew = 0;    // test aid (sc_selfplay_debug_break_handoff): arrivals that will never come
 };
 
 // complete the last enqueued simulation (expand / backward / ply transition) so that host reads see a
@@ -805,7 +806,7 @@ int sc_selfplay_enqueue_sims(sc_selfplay* sp, int n) {
             t.dbg_stage = -1;
             if (sp->fc1_in_step) {
                 t.fc1_arrive = sp->d_fc1_ctr;
-                t.fc1_target = 64u * ++sp->fc1_launches;   // every workgroup of a block arrives once per launch (wraps with the counter)
+                t.fc1_target = 64u * ++sp->fc1_launches + sp->fc1_target_skew;   // every workgroup of a block arrives once per launch (wraps with the counter)
                 t.vpart = sp->d_vpart;
                 t.fc1_acquire = e->step_blocks_per_cu > 1;
                 scl::step(t, q, 1, s);
@@ -1080,6 +1081,13 @@ int sc_selfplay_poll(sc_selfplay* sp, int32_t* finished_games, int cap) {
         if (p.trace_hold) sp->to_release.push_back(f.second);
     }
     return n;
+}
+
+int sc_selfplay_debug_break_handoff(sc_selfplay* sp, int missing) {
+    if (!sp) return fail("null handle");
+    if (!sp->fc1_in_step) return 1;
+    sp->fc1_target_skew += (uint32_t)missing;
+    return 0;
 }
 
 int sc_debug_find_max(int device_id, const float* values, int n, int32_t* out2) {

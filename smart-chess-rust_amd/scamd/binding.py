@@ -55,6 +55,7 @@ ABI = {
     "sc_last_warning": (C.c_char_p, []),
     "sc_selfplay_poll": (_i, [_vp, _vp, _i]),
     "sc_debug_find_max": (_i, [_i, _vp, _i, _vp]),
+    "sc_selfplay_debug_break_handoff": (_i, [_vp, _i]),
     "sc_selfplay_debug_cycles": (_i, [_vp, _i, _vp]),
     "sc_engine_create": (_i, [C.POINTER(NetConfig), C.c_char_p, _i, C.POINTER(_vp)]),
     "sc_engine_destroy": (None, [_vp]),

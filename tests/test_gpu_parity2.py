@@ -528,3 +528,31 @@ def test_one_launch_form_is_granted_to_one_stream_per_device(scamd):
     for h in (b, d, f):
         h.close()
     e1.close(); e2.close()
+
+
+def test_in_launch_handoff_wait_is_bounded(scamd):
+    """the one-launch step's workgroups wait for each other inside the launch; a wait that can never be satisfied (test aid:
+    the arrival target is raised by one) must end by itself: every workgroup gives up after ~0.2 s, the launch completes and
+    the handle reports error bit 32 -- nothing hangs"""
+    import time
+    eng = scamd.Engine(1, 128, seed=2)
+    sp = scamd.SelfPlay(eng, n_slots=64, n_games=64, rollout_num=8, num_steps=4, cpuct=2.5, seed=1)
+    assert sp.launches_per_step() == 1
+    sp.enqueue(4)
+    sp.sync()
+    assert sp.stats()["error_flags"] == 0
+    assert scamd.lib().sc_selfplay_debug_break_handoff(sp.h, 1) == 0
+    t0 = time.time()
+    sp.enqueue(2)
+    sp.sync()
+    dt = time.time() - t0
+    assert sp.stats()["error_flags"] & 32
+    assert 0.15 < dt < 5.0, dt          # two launches x ~0.2 s
+    sp.close()
+    # a handle without the one-launch form is not affected
+    sp2 = scamd.SelfPlay(eng, n_slots=24, n_games=24, rollout_num=8, num_steps=4, cpuct=2.5, seed=1)
+    assert scamd.lib().sc_selfplay_debug_break_handoff(sp2.h, 1) == 1
+    sp2.run()
+    assert sp2.stats()["error_flags"] == 0 and sp2.stats()["games_finished"] == 24
+    sp2.close()
+    eng.close()
