@@ -133,13 +133,17 @@ def run_gpu(args, rank, world, local_rank):
                  ("fp8", args.channels, args.games, 1), ("fp8_512", args.channels, 2 * args.games, 1),
                  # a random-init net has nearly flat priors (shallow trees); a trained one is sharp.  Same weights with the
                  # policy head's last LayerNorm gain x 8: the search descends deeper, the network cost is unchanged
-                 ("sharp", args.channels, args.games, 1)]
+                 ("sharp", args.channels, args.games, 1),
+                 # BASELINE configs[3]'s per-GPU slice: 20 blocks x 256 channels, rollout 800 (one timed ply)
+                 ("deep", 256, args.games, 1)]
     for tag, C, G, K in runs:
         prec = "fp8" if tag.startswith("fp8") else args.precision
+        R = 800 if tag == "deep" else args.rollout
+        blocks = 20 if tag == "deep" else args.blocks
         if tag == "sharp":
             eng = sharp_prior_engine(scamd, args.blocks, C, local_rank, prec)
         else:
-            eng = scamd.Engine(args.blocks, C, seed=1, device=local_rank, precision=prec)
+            eng = scamd.Engine(blocks, C, seed=1, device=local_rank, precision=prec)
         assert G % K == 0
         sps = [scamd.SelfPlay(eng, n_slots=G // K, n_games=10 ** 7 // K, trace_capacity=4 * G // K, rollout_num=R, num_steps=150,
                               cpuct=2.5, temperature=0.0, temperature_switch=4, epsilon=0.15, with_noise=True, seed=1234,
@@ -159,10 +163,10 @@ def run_gpu(args, rank, world, local_rank):
                     tot[k] = tot.get(k, 0) + v if k != "error_flags" else tot.get(k, 0) | v
             return tot
 
-        steps = args.steps if tag == "main" else max(2, args.steps // 4)
+        steps = args.steps if tag == "main" else 1 if tag == "deep" else max(2, args.steps // 4)
         if tag == "steady":
             seed_mid_game_positions(scamd, eng, sps[0], G, R)
-        enqueue(args.warmup * R)
+        enqueue((1 if tag == "deep" else args.warmup) * R)
         for sp in sps:
             sp.enable_timing(args.timing_stride)
             sp.timing(reset=True)
@@ -189,7 +193,7 @@ def run_gpu(args, rank, world, local_rank):
         tms = [sp.timing() for sp in sps]
         s1 = stats()
         nl = sum(t["tower_launches"] for t in tms)
-        res[tag] = dict(C=C, precision=prec, regions=regions, steps=steps, nn_evals=s1["nn_evals"] - nn0["nn_evals"],
+        res[tag] = dict(C=C, precision=prec, regions=regions, steps=steps, blocks=blocks, rollout=R, nn_evals=s1["nn_evals"] - nn0["nn_evals"],
                         sims_all=s1["sims_done"] - nn0["sims_done"], err=s1["error_flags"],
                         tower_ms=sum(t["ms_tower_sum"] for t in tms) / max(nl, 1), tower_launches=nl,
                         span_ms=max(t["ms_total"] for t in tms), groups=K, games=G)
@@ -414,6 +418,16 @@ def main():
                                "tower_avg_ms": round(a["tower_ms"], 4),
                                "roofline_frac": round(args.games * fa / (a["tower_ms"] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4)
                                if a["tower_ms"] > 0 else None}
+            if "deep" in res:
+                x = res["deep"]
+                fd = 2.0 * macs_per_position(x["blocks"], x["C"], tower_only=True)
+                v, ms = rate(x)
+                out["also_deep"] = {"config": "BASELINE configs[3], one GPU's slice: 20 blocks x 256 channels bf16, rollout 800, "
+                                              f"{x['games']} concurrent games (one timed ply)",
+                                    "net": f"{x['blocks']}x{x['C']}", "rollout": x["rollout"], "value": round(v, 1), "ms_per_step": round(ms, 3),
+                                    "tower_avg_ms": round(x["tower_ms"], 4), "error_flags": x["err"],
+                                    "roofline_frac": round(x["games"] * fd / (x["tower_ms"] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4)
+                                    if x["tower_ms"] > 0 else None}
             for tag in ("fp8", "fp8_512"):
                 if tag in res:
                     x = res[tag]
