@@ -995,8 +995,16 @@ int sc_selfplay_get_trace(sc_selfplay* sp, int game, sc_trace_info* info, uint16
     const uint64_t want_id = sp->p.first_game_id + (uint64_t)game;
     game %= sp->p.trace_cap;
     HIPOK(hipSetDevice(sp->device));
-    sp_flush(sp);
-    HIPOK(hipStreamSynchronize(sp->stream));
+    // A row that sc_selfplay_poll has reported and holds (trace_hold) is final and no kernel writes it until the next poll
+    // releases it: it is read without waiting for the stream, so a consumer can enqueue the next simulation steps first and
+    // fetch / write the finished traces while they run (the copies below are on the NULL stream; the launch stream is
+    // non-blocking).  Anything else is read from an idle stream.
+    const bool held = sp->p.trace_hold && sp->reported[(size_t)game] == want_id + 1 &&
+                      std::find(sp->to_release.begin(), sp->to_release.end(), game) != sp->to_release.end();
+    if (!held) {
+        sp_flush(sp);
+        HIPOK(hipStreamSynchronize(sp->stream));
+    }
     const sc::SpParams& p = sp->p;
     sc::TraceHdr h;
     HIPOK(hipMemcpy(&h, p.thdr + game, sizeof h, hipMemcpyDeviceToHost));

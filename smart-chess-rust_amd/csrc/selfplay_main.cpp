@@ -21,6 +21,7 @@
 
 #include <string>
 #include <thread>
+#include <utility>
 #include <vector>
 
 #include "../../include/sc_engine.h"
@@ -142,42 +143,47 @@ static int run_gpu(const Args& a, int gpu, int first, int count, int* finished_w
         sps.push_back(sp);
         off += cnt;
     }
-    // interleave the groups simulation step by simulation step; after every chunk (one ply's worth of steps) write the
-    // traces of the games that have ended
+    // interleave the groups simulation step by simulation step; after every chunk (one ply's worth of steps) the games that
+    // have ended are collected (sc_selfplay_poll: their trace rows stay untouched until the next poll), the NEXT chunk is
+    // enqueued, and only then are their traces fetched and written -- the GPU searches while the host formats JSON
     int with_outcome = 0, finished = 0, errs = 0, written = 0;
     long long sims = 0;
     const int chunk = a.rollout_num > 0 ? a.rollout_num : 300;
     std::vector<int32_t> fin(4096);
+    std::vector<std::pair<size_t, int32_t>> todo;   // (group, game) reported by the polls of this round
+    rc = sc_selfplay_enqueue_interleaved(sps.data(), (int)sps.size(), chunk);
     while (!rc) {
-        rc = sc_selfplay_enqueue_interleaved(sps.data(), (int)sps.size(), chunk);
-        if (rc) break;
         int active = 0;
+        bool more = false;   // a poll filled its buffer: poll again before anything else is enqueued
+        todo.clear();
         for (size_t k = 0; k < sps.size() && !rc; k++) {
             sc_selfplay* sp = sps[k];
-            for (;;) {
-                const int n = sc_selfplay_poll(sp, fin.data(), (int)fin.size());
-                if (n < 0) {
-                    rc = 1;
-                    break;
-                }
-                for (int i = 0; i < n && !rc; i++) {
-                    sc_trace_info info{};
-                    if (sc_selfplay_get_trace(sp, fin[(size_t)i], &info, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr)) {
-                        rc = 1;
-                        break;
-                    }
-                    with_outcome += info.has_outcome;
-                    std::string path = trace_name(a, info.game_id + 1);
-                    if (sc_selfplay_write_trace_json(sp, fin[(size_t)i], path.c_str())) rc = 1;
-                    else written++;
-                }
-                if (n < (int)fin.size() || rc) break;
+            const int n = sc_selfplay_poll(sp, fin.data(), (int)fin.size());
+            if (n < 0) {
+                rc = 1;
+                break;
             }
+            for (int i = 0; i < n; i++) todo.emplace_back(k, fin[(size_t)i]);
+            more = more || n == (int)fin.size();
             sc_selfplay_stats st{};
-            if (!rc && sc_selfplay_get_stats(sp, &st)) rc = 1;
+            if (sc_selfplay_get_stats(sp, &st)) rc = 1;
             active += st.games_active;
         }
-        if (rc || active == 0) break;
+        if (rc) break;
+        if (active > 0 && !more) rc = sc_selfplay_enqueue_interleaved(sps.data(), (int)sps.size(), chunk);
+        for (size_t i = 0; i < todo.size() && !rc; i++) {
+            sc_selfplay* sp = sps[todo[i].first];
+            sc_trace_info info{};
+            if (sc_selfplay_get_trace(sp, todo[i].second, &info, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr)) {
+                rc = 1;
+                break;
+            }
+            with_outcome += info.has_outcome;
+            std::string path = trace_name(a, info.game_id + 1);
+            if (sc_selfplay_write_trace_json(sp, todo[i].second, path.c_str())) rc = 1;
+            else written++;
+        }
+        if (rc || (active == 0 && !more)) break;
     }
     if (rc) fprintf(stderr, "gpu %d: %s\n", gpu, sc_last_error());
     for (size_t k = 0; k < sps.size(); k++) {
