@@ -547,6 +547,25 @@ class SelfPlay:
     def write_trace(self, game, path):
         _check(self.L.sc_selfplay_write_trace_json(self.h, game, path.encode()))
 
+    def stream_traces(self, path_of, chunk=None):
+        """The loop of lib/sc-selfplay (src/main.rs:235-238 writes each game's file when it ends): plays every game of the
+        handle and writes `path_of(game_id)` as games finish, from a handle created with a trace ring and trace_hold=True.
+        The next ply's simulation steps are enqueued BEFORE the finished games' traces are fetched and written: a reported
+        row is final, it is read while the GPU searches.  -> number of files written."""
+        chunk = chunk or self.cfg.rollout_num
+        written = 0
+        self.enqueue(chunk)
+        while True:
+            fin = self.poll()
+            active = self.stats()["games_active"]
+            if active:
+                self.enqueue(chunk)
+            for g in fin:
+                self.write_trace(g, path_of(self.cfg.first_game_id + g))
+                written += 1
+            if not active and not fin:
+                return written
+
     def tree(self, slot, cap=1 << 20):
         n = self.L.sc_selfplay_get_tree(self.h, slot, 0, None, None, None, None, None, None, None)
         if n < 0:

@@ -346,6 +346,26 @@ def test_poll_streams_every_game_once(scamd, orc):
     sp.close()
 
 
+def test_traces_read_while_the_next_ply_runs(scamd, tmp_path):
+    """the pipelined streaming loop (lib/sc-selfplay, SelfPlay.stream_traces): finished games are reported by the poll, the next
+    ply's steps are enqueued, and only then are the reported traces fetched and written -- a held row is final, so reading it
+    beside the running kernels gives byte-identical files to reading everything from an idle handle at the end"""
+    eng = scamd.Engine(2, 128, seed=5)
+    cfg = dict(n_slots=64, n_games=200, rollout_num=12, num_steps=10, cpuct=2.5, temperature=0.6, temperature_switch=3, with_noise=True, seed=21,
+               outcome_gate=0)
+    ref = scamd.SelfPlay(eng, **cfg)                       # all trace rows kept, read at the end
+    ref.run()
+    sp = scamd.SelfPlay(eng, trace_capacity=2 * 64 + 8, trace_hold=True, first_game_id=0, **cfg)
+    n = sp.stream_traces(lambda gid: str(tmp_path / f"s{gid}.json"))
+    assert n == 200 and sp.stats()["error_flags"] == 0 and sp.stats()["games_finished"] == 200
+    for g in range(200):
+        ref.write_trace(g, str(tmp_path / f"r{g}.json"))
+        assert open(tmp_path / f"r{g}.json").read() == open(tmp_path / f"s{g}.json").read(), g
+    sp.close()
+    ref.close()
+    eng.close()
+
+
 # ---------------------------------------------------------------------------------- multi-GPU readiness (8e)
 def test_disjoint_handles_stand_in_for_ranks(scamd, tmp_path):
     """games shard by id: two handles with disjoint first_game_id ranges -- what two ranks / two GPUs run --
