@@ -576,3 +576,18 @@ def test_in_launch_handoff_wait_is_bounded(scamd):
     assert sp2.stats()["error_flags"] == 0 and sp2.stats()["games_finished"] == 24
     sp2.close()
     eng.close()
+
+
+def test_step_form_chosen_for_the_baseline_configurations(scamd):
+    """which pipeline form a handle gets is a property of the build (registers and LDS of the fused kernel decide how many of its
+    workgroups fit a CU): BASELINE configs[1] (256 bf16 games) and configs[4]'s per-GPU share (512 fp8 games) must get the
+    one-launch step -- a kernel change that costs the second fp8 workgroup per CU would otherwise pass every parity test and
+    silently lose 10 % (measured once)"""
+    bf, f8 = scamd.Engine(1, 128, seed=1), scamd.Engine(1, 128, seed=1, precision="fp8")
+    want = [(bf, 256, 1), (bf, 192, 1), (bf, 100, 2), (bf, 512, 3), (f8, 256, 1), (f8, 512, 1), (f8, 500, 2)]
+    for eng, slots, launches in want:
+        sp = scamd.SelfPlay(eng, n_slots=slots, n_games=slots, rollout_num=4, num_steps=2)
+        assert sp.launches_per_step() == launches, (eng.precision, slots, sp.launches_per_step())
+        sp.close()
+    bf.close()
+    f8.close()
