@@ -591,3 +591,30 @@ def test_step_form_chosen_for_the_baseline_configurations(scamd):
         sp.close()
     bf.close()
     f8.close()
+
+
+@pytest.mark.parametrize("black", [(1, 256, "bf16"), (2, 128, "fp8")])
+def test_match_play_one_launch_equals_separate_launches(scamd, black):
+    """match play alternates two networks by ply (src/play.rs:318-343): with 64 games the step is one launch whose value FC
+    tiles use THIS ply's network while the next launch's value tail finishes the position with the PREVIOUS ply's -- the games
+    must equal those of the three-launch form, for players of different width and of different precision"""
+    w = scamd.Engine(2, 128, seed=1)
+    b = scamd.Engine(black[0], black[1], seed=2, precision=black[2])
+    cfg = dict(n_slots=64, n_games=64, rollout_num=10, num_steps=12, cpuct=1.5, temperature=0.0, with_noise=False, outcome_gate=-1, seed=4,
+               tie_random=True)
+    x = scamd.SelfPlay(w, **cfg)
+    x.set_players(w, b)
+    assert x.launches_per_step() == 1
+    x.run()
+    y = scamd.SelfPlay(w, **cfg)
+    y.set_players(w, b)
+    y.enable_timing(1)
+    y.run()
+    for g in range(64):
+        tx = x.trace(g)
+        assert tx is not None and tx == y.trace(g), g
+    assert x.stats() == y.stats() and x.stats()["error_flags"] == 0
+    for h in (x, y):
+        h.close()
+    w.close()
+    b.close()
