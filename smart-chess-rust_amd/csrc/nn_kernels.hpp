@@ -134,18 +134,21 @@ __device__ inline int chan0(int wave, int lane) { return wave * (16 * NTW) + (la
 // Split-K >= 64 (the launchers check): a tile is at most 8 k-steps and its weights fit one register batch.
 constexpr int AUX_SC1 = 16;   // cache-policy bits of the gfx942/gfx950 buffer builtins: 1 = sc0, 2 = nt, 16 = sc1
 struct Fc1W {
-    bf16x8 b[8][2];
+    bf16x8 b[8][4];
 };
 constexpr int FC1_TILE_LDS = 64 * (FC1_K / 64 + 8) * 2;   // bytes of the staged feature rows (33 KB)
+// Wave w computes rows 32 (w >> 1) .. +31 x column tiles 4 (w & 1) .. +3 of the 64 x 128 tile: with each wave on 64 rows x 2 column
+// tiles the four waves read every staged row four times (128 KB of LDS reads against 1 024 cycles of MFMA); 2 x 2 halves that
+// (each output element is still the same chain of MFMAs on the same operands: the partial sums do not change by a bit).
 __device__ __forceinline__ void fc1_wload(Fc1W& w, const NetDev& net, int ks, int ksplit, int wave, int lane) {
     const int steps = FC1_K / ksplit / 32;
-    const bf16x8* Wv = reinterpret_cast<const bf16x8*>(net.wb + net.o_fc1) + ((size_t)(ks * steps) * 8 + wave * 2) * 64 + lane;
+    const bf16x8* Wv = reinterpret_cast<const bf16x8*>(net.wb + net.o_fc1) + ((size_t)(ks * steps) * 8 + (wave & 1) * 4) * 64 + lane;
     // the tile is a short dependent chain: all its weight loads are in flight before the first MFMA
 #pragma unroll
     for (int u = 0; u < 8; u++) {
         const int s = u < steps ? u : steps - 1;
-        w.b[u][0] = Wv[((size_t)s * 8 + 0) * 64];
-        w.b[u][1] = Wv[((size_t)s * 8 + 1) * 64];
+#pragma unroll
+        for (int i = 0; i < 4; i++) w.b[u][i] = Wv[((size_t)s * 8 + i) * 64];
     }
 }
 // The 64 feature rows of the tile are the same for all four waves (each owns 32 of the 128 output columns): they go
@@ -190,30 +193,36 @@ __device__ __forceinline__ void fc1_mma_store(const Fc1W& w, const bf16_t* s_a, 
                                               int wave, int lane) {
     const int kchunk = FC1_K / ksplit, steps = kchunk / 32, apitch = kchunk + 8;
     const int row16 = lane & 15, kq = lane >> 4;
-    f32x4 acc[4][2];
+    const int mt0 = 2 * (wave >> 1), ct0 = 4 * (wave & 1);
+    f32x4 acc[2][4];
 #pragma unroll
-    for (int mt = 0; mt < 4; mt++)
+    for (int m = 0; m < 2; m++)
 #pragma unroll
-        for (int i = 0; i < 2; i++) acc[mt][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < 4; i++) acc[m][i] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int u = 0; u < 8; u++) {
         if (u < steps) {
 #pragma unroll
-            for (int mt = 0; mt < 4; mt++) {
-                const bf16x8 a = *reinterpret_cast<const bf16x8*>(s_a + (mt * 16 + row16) * apitch + u * 32 + 8 * kq);
-                acc[mt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, w.b[u][0], acc[mt][0], 0, 0, 0);
-                acc[mt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, w.b[u][1], acc[mt][1], 0, 0, 0);
+            for (int m = 0; m < 2; m++) {
+                const bf16x8 a = *reinterpret_cast<const bf16x8*>(s_a + ((mt0 + m) * 16 + row16) * apitch + u * 32 + 8 * kq);
+#pragma unroll
+                for (int i = 0; i < 4; i++) acc[m][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, w.b[u][i], acc[m][i], 0, 0, 0);
             }
         }
     }
-    const int c0 = chan0<2>(wave, lane);
+    // column tile t, lane column c (the host's packing, chan0<2>): output channel (t >> 1) * 32 + c * 2 + (t & 1)
 #pragma unroll
-    for (int mt = 0; mt < 4; mt++)
+    for (int m = 0; m < 2; m++)
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-            const int row = mb * 64 + mt * 16 + (lane >> 4) * 4 + r;
-            if (row < n_pos)
-                *reinterpret_cast<float2*>(vpart + ((size_t)ks * n_pos + row) * FC1_N + c0) = make_float2(acc[mt][0][r], acc[mt][1][r]);
+            const int row = mb * 64 + (mt0 + m) * 16 + (lane >> 4) * 4 + r;
+            if (row < n_pos) {
+#pragma unroll
+                for (int j = 0; j < 2; j++) {
+                    const int c0 = ((ct0 >> 1) + j) * 32 + (lane & 15) * 2;
+                    *reinterpret_cast<float2*>(vpart + ((size_t)ks * n_pos + row) * FC1_N + c0) = make_float2(acc[m][2 * j][r], acc[m][2 * j + 1][r]);
+                }
+            }
         }
 }
 
