@@ -618,3 +618,25 @@ def test_match_play_one_launch_equals_separate_launches(scamd, black):
         h.close()
     w.close()
     b.close()
+
+
+@pytest.mark.parametrize("precision,n_slots", [("bf16", 256), ("fp8", 512)])
+def test_baseline_configuration_one_launch_equals_separate_launches(scamd, precision, n_slots):
+    """BASELINE configs[1] / configs[4] sizing exactly (10 x 128 net, rollout 180, 256 bf16 / 512 fp8 games) for a few plies:
+    the one-launch step and the three-launch form play the same games"""
+    eng = scamd.Engine(10, 128, seed=1, precision=precision)
+    cfg = dict(n_slots=n_slots, n_games=n_slots, rollout_num=180, num_steps=3, cpuct=2.5, temperature=0.0, temperature_switch=4, epsilon=0.15,
+               with_noise=True, seed=1234)
+    a = scamd.SelfPlay(eng, **cfg)
+    assert a.launches_per_step() == 1
+    a.run()
+    b = scamd.SelfPlay(eng, **cfg)
+    b.enable_timing(1)
+    b.run()
+    for g in range(0, n_slots):
+        ta = a.trace(g)
+        assert ta is not None and len(ta["steps"]) == 3 and ta == b.trace(g), g
+    assert a.stats() == b.stats() and a.stats()["error_flags"] == 0
+    for h in (a, b):
+        h.close()
+    eng.close()
