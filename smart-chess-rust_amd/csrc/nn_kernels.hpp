@@ -60,6 +60,28 @@ __device__ __forceinline__ float wave_max64(float v) {
     return fmaxf(fmaxf(readlane_f(v, 0), readlane_f(v, 16)), fmaxf(readlane_f(v, 32), readlane_f(v, 48)));
 }
 
+// The kernel arguments live in memory that is fresh at every launch, and the compiler reads them piece by piece where they are
+// first needed, each piece behind its own wait: a chain of scalar-cache misses at the top of every kernel (stamped in the fused
+// step kernel: 8.7 k -> 6.6 k cycles from the first instruction to the arrival of the search's control block).  One scalar load
+// per 64-byte line of the argument block, all in flight together, makes the chain one miss deep (+0.5 % / +1.3 % simulations/s
+// at bf16 / fp8; the stand-alone tower launch, whose prologue has more to hide it under, measured no change and does not use it).  (One asm statement with its
+// own wait inside: the compiler does not count the loads of an asm statement, and the destination registers must not be reused
+// before the loads have landed.)
+template <int BYTES>
+__device__ __forceinline__ void kernarg_prefetch() {
+    constexpr int LINES = (BYTES + 63) / 64;
+    static_assert(LINES == 11, "the statement below reads eleven lines: exactly the argument block of the fused step kernel");
+    const unsigned long long ka = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
+    uint32_t t0, t1, t2, t3, t4, t5, t6, t7, t8, t9, t10;
+    asm volatile(
+        "s_load_dword %0, %11, 0x0\n\ts_load_dword %1, %11, 0x40\n\ts_load_dword %2, %11, 0x80\n\ts_load_dword %3, %11, 0xc0\n\t"
+        "s_load_dword %4, %11, 0x100\n\ts_load_dword %5, %11, 0x140\n\ts_load_dword %6, %11, 0x180\n\ts_load_dword %7, %11, 0x1c0\n\t"
+        "s_load_dword %8, %11, 0x200\n\ts_load_dword %9, %11, 0x240\n\ts_load_dword %10, %11, 0x280\n\ts_waitcnt lgkmcnt(0)"
+        : "=&s"(t0), "=&s"(t1), "=&s"(t2), "=&s"(t3), "=&s"(t4), "=&s"(t5), "=&s"(t6), "=&s"(t7), "=&s"(t8), "=&s"(t9), "=&s"(t10)
+        : "s"(ka)
+        : "memory");
+}
+
 // haloed image index of pixel p (0..63)
 __device__ inline int hidx(int p) { return ((p >> 3) + 1) * 10 + (p & 7) + 1; }
 

@@ -99,23 +99,8 @@ __global__ __launch_bounds__(256, 1) void k_step(scnn::TowerArgs A, sc::SpParams
     __shared__ sc::HelperBox s_box;
     const int g = blockIdx.x;
     const int lane = threadIdx.x & 63;
-    // The two argument blocks are 684 bytes = 11 cache lines of kernel-argument memory, fresh at every launch.  The compiler reads
-    // them piece by piece where they are first needed (there are not enough SGPRs to hold them), each piece behind its own
-    // s_waitcnt: some fourteen scalar-cache misses in a row, 4.6 k cycles from the kernel's first instruction to the first
-    // instruction of the search (stamps) and more inside it.  One scalar load per line up front makes them one miss deep.
-    {
-        static_assert(sizeof(scnn::TowerArgs) + sizeof(sc::SpParams) + sizeof(int) <= 11 * 64, "one scalar load per 64-byte line of the arguments");
-        const unsigned long long ka = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
-        uint32_t t0, t1, t2, t3, t4, t5, t6, t7, t8, t9, t10;
-        // (one statement, its own wait inside: the compiler does not count the loads of an asm statement)
-        asm volatile(
-            "s_load_dword %0, %11, 0x0\n\ts_load_dword %1, %11, 0x40\n\ts_load_dword %2, %11, 0x80\n\ts_load_dword %3, %11, 0xc0\n\t"
-            "s_load_dword %4, %11, 0x100\n\ts_load_dword %5, %11, 0x140\n\ts_load_dword %6, %11, 0x180\n\ts_load_dword %7, %11, 0x1c0\n\t"
-            "s_load_dword %8, %11, 0x200\n\ts_load_dword %9, %11, 0x240\n\ts_load_dword %10, %11, 0x280\n\ts_waitcnt lgkmcnt(0)"
-            : "=&s"(t0), "=&s"(t1), "=&s"(t2), "=&s"(t3), "=&s"(t4), "=&s"(t5), "=&s"(t6), "=&s"(t7), "=&s"(t8), "=&s"(t9), "=&s"(t10)
-            : "s"(ka)
-            : "memory");
-    }
+    // the two argument blocks: 684 bytes = 11 cache lines (kernarg_prefetch, nn_kernels.hpp)
+    scnn::kernarg_prefetch<sizeof(scnn::TowerArgs) + sizeof(sc::SpParams) + sizeof(int)>();
     // wave 0: the game's search, wave 1: its helper (encodes the leaf's planes while wave 0 generates the moves); both run
     // inside the tower's prologue (tower_body, Pre), after every wave has requested its first weights
     if (threadIdx.x == 0) s_box.state = 0;   // LDS starts with whatever the previous workgroup left: clear the mailbox ...
