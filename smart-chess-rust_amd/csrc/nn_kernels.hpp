@@ -70,7 +70,7 @@ __device__ __forceinline__ float wave_max64(float v) {
 template <int BYTES>
 __device__ __forceinline__ void kernarg_prefetch() {
     constexpr int LINES = (BYTES + 63) / 64;
-    static_assert(LINES == 11, "the statement below reads eleven lines: exactly the argument block of the fused step kernel");
+    static_assert(LINES == 11 && BYTES >= 0x284, "the statement below reads eleven lines: exactly the argument block of the fused step kernel");
     const unsigned long long ka = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
     uint32_t t0, t1, t2, t3, t4, t5, t6, t7, t8, t9, t10;
     asm volatile(
