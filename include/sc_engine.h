@@ -262,8 +262,8 @@ int sc_debug_find_max(int device_id, const float* values, int n, int32_t* out2);
  * the launch ends and error_flags carries bit 32.  The handle's results are invalid afterwards.  No effect (returns 1) on a
  * handle that does not use the one-launch form. */
 int sc_selfplay_debug_break_handoff(sc_selfplay*, int missing);
-/* developer aid: stamps of the last launch, out[n_slots][16]: 0..7 the search's cycle stamps (tools/dbg_cycles.py), 8..15
- * written by experiment builds only (tools/dbg_tail.py) */
+/* developer aid: stamps of the last launch, out[n_slots][32]: 0..7 the search's cycle stamps (tools/dbg_cycles.py), 8.. written
+ * by experiment builds only (tools/dbg_tail.py, tools/dbg_expand.py) */
 int sc_selfplay_debug_cycles(sc_selfplay*, int enable, unsigned long long* out);
 
 /* utility: trace-file JSON writer on caller-provided arrays (no GPU needed) */

@@ -1295,13 +1295,13 @@ int sc_selfplay_debug_cycles(sc_selfplay* sp, int enable, unsigned long long* ou
     HIPOK(hipSetDevice(sp->device));
     HIPOK(hipStreamSynchronize(sp->stream));
     if (enable && !sp->p.dbg_cycles) {
-        HIPOK(dalloc(&sp->p.dbg_cycles, (size_t)sp->p.n_slots * 16));
+        HIPOK(dalloc(&sp->p.dbg_cycles, (size_t)sp->p.n_slots * 32));
         sp->allocs.push_back(sp->p.dbg_cycles);
-        HIPOK(hipMemset(sp->p.dbg_cycles, 0, (size_t)sp->p.n_slots * 128));
+        HIPOK(hipMemset(sp->p.dbg_cycles, 0, (size_t)sp->p.n_slots * 256));
         HIPOK(hipDeviceSynchronize());
     }
     if (out && sp->p.dbg_cycles)
-        HIPOK(hipMemcpy(out, sp->p.dbg_cycles, (size_t)sp->p.n_slots * 128, hipMemcpyDeviceToHost));
+        HIPOK(hipMemcpy(out, sp->p.dbg_cycles, (size_t)sp->p.n_slots * 256, hipMemcpyDeviceToHost));
     return 0;
 }
 

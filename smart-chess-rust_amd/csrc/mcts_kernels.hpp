@@ -307,9 +307,14 @@ __device__ inline float gamma03(uint64_t st) {
 // ------------------------------------------------------------------ select (src/mcts.rs:132-227)
 constexpr int DEPTH_LDS = 1024;  // path entries tracked in LDS (a deeper path sets ERR_DEPTH_OVERFLOW)
 
+#ifdef SC_EXP   // experiment builds: stamps inside the expansion (slots 16..), tools/dbg_expand.py
+#define SC_XSTAMP(k) SC_STAMP(k)
+#else
+#define SC_XSTAMP(k)
+#endif
 #define SC_STAMP(k)                                                                   \
     do {                                                                              \
-        if (p.dbg_cycles && lane == 0) p.dbg_cycles[(size_t)g * 16 + (k)] = clock64(); \
+        if (p.dbg_cycles && lane == 0) p.dbg_cycles[(size_t)g * 32 + (k)] = clock64(); \
     } while (0)
 
 // Hand-off to a helper wavefront (fused step kernel): once the leaf position and its repetition flags stand, the plane
@@ -543,7 +548,7 @@ __device__ __forceinline__ bool dev_select(const SpParams& p, int g, int lane, i
         }
     }
     SC_STAMP(3);
-    if (p.dbg_cycles && lane == 0) p.dbg_cycles[(size_t)g * 16 + 7] = depth;   // developer stamp: levels walked
+    if (p.dbg_cycles && lane == 0) p.dbg_cycles[(size_t)g * 32 + 7] = depth;   // developer stamp: levels walked
     unsigned long long anyerr = __ballot(err != 0);
     if (anyerr) {
         for (int o = 32; o > 0; o >>= 1) err |= __shfl_xor(err, o, 64);
@@ -930,7 +935,9 @@ __device__ __forceinline__ void dev_expand(SpParams& p, int g, int lane, Positio
     ValueTail vt;
     if (p.vf_fused) value_tail_issue(p, g, lane, vt);   // used when the leaf turns out to be a network evaluation
     __builtin_amdgcn_sched_barrier(0);
+    SC_XSTAMP(16);
     const GameCtl cs = uniform(craw);
+    SC_XSTAMP(17);
     const int pth = lane < p.max_depth ? pth_raw : 0;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
@@ -973,6 +980,7 @@ __device__ __forceinline__ void dev_expand(SpParams& p, int g, int lane, Positio
     }
     if (kind == LK_EVAL) {
         value = p.vf_fused ? value_tail_finish(p, vt) : p.value[g];
+        SC_XSTAMP(18);
         int n = cs.n_legal;
         if (n_nodes + n > p.node_cap || n_exp + 1 >= p.tpos_cap) {
             err = ERR_POOL_OVERFLOW;
@@ -997,6 +1005,7 @@ __device__ __forceinline__ void dev_expand(SpParams& p, int g, int lane, Positio
     } else if (kind == LK_TERM_NEW) {
         if (lane == 0) H[leaf] = NodeHdr{value == 0.0f ? -2 : value > 0.0f ? -3 : -4, 0, 0};
     }
+    SC_XSTAMP(19);
     // backward (mcts.rs:90-98): every node of the path, root included
     if (inpath) {
         N[pth] = n0 + 1;
@@ -1023,6 +1032,7 @@ __device__ __forceinline__ void dev_expand(SpParams& p, int g, int lane, Positio
         p.slot_cnt[(size_t)g * 2] = sc_sims + 1ULL;
         if (kind == LK_EVAL) p.slot_cnt[(size_t)g * 2 + 1] = sc_evals + 1ULL;
     }
+    SC_XSTAMP(20);
     cs_out.n_nodes = n_nodes;
     cs_out.n_exp = n_exp;
     cs_out.sim = sim;

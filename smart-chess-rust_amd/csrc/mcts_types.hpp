@@ -85,7 +85,7 @@ struct SpParams {
     const float* vpart;
     const float* vf_w;
     uint32_t vf_fc1b, vf_fc1m, vf_fc2w, vf_fc2b;
-    unsigned long long* dbg_cycles;  // optional [slot][16] stamps of the last launch (developer aid): 0..7 the search's cycle stamps, 8..15 experiment builds
+    unsigned long long* dbg_cycles;  // optional [slot][32] stamps of the last launch (developer aid): 0..7 the search's cycle stamps, 8.. experiment builds
 };
 
 

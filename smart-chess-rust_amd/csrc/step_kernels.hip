@@ -40,7 +40,7 @@ __device__ __forceinline__ void fc1_tail(const scnn::TowerArgs& A, const sc::SpP
     const int mb = g >> 6, ks = g & 63;
     uint32_t* ctr = A.fc1_arrive + mb * 32;
 #ifdef SC_EXP   // experiment builds: stamps of the tail's phases (100 MHz), read by tools/dbg_tail.py
-#define TSTAMP(k) do { if (p.dbg_cycles && tid == 0) p.dbg_cycles[(size_t)g * 16 + 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define TSTAMP(k) do { if (p.dbg_cycles && tid == 0) p.dbg_cycles[(size_t)g * 32 + 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define TSTAMP(k)
 #endif
@@ -56,7 +56,7 @@ __device__ __forceinline__ void fc1_tail(const scnn::TowerArgs& A, const sc::SpP
     const scnn::Fc1W& w = fh.w;
     const bool have_a = ran && fh.have_a;   // (uniform over the workgroup)
 #ifdef SC_EXP
-    if (p.dbg_cycles && tid == 0) p.dbg_cycles[(size_t)g * 16 + 14] = have_a;
+    if (p.dbg_cycles && tid == 0) p.dbg_cycles[(size_t)g * 32 + 14] = have_a;
     if (have_a) { TSTAMP(1); TSTAMP(2); }
 #endif
     if (tid == 0 && !have_a) {
@@ -99,8 +99,14 @@ __global__ __launch_bounds__(256, 1) void k_step(scnn::TowerArgs A, sc::SpParams
     __shared__ sc::HelperBox s_box;
     const int g = blockIdx.x;
     const int lane = threadIdx.x & 63;
+#ifdef SC_EXP
+    const long long t_entry = clock64();   // experiment builds: the kernel's first instruction (tools/dbg_expand.py)
+#endif
     // the two argument blocks: 684 bytes = 11 cache lines (kernarg_prefetch, nn_kernels.hpp)
     scnn::kernarg_prefetch<sizeof(scnn::TowerArgs) + sizeof(sc::SpParams) + sizeof(int)>();
+#ifdef SC_EXP
+    if (p.dbg_cycles && threadIdx.x == 0) p.dbg_cycles[(size_t)g * 32 + 21] = t_entry;
+#endif
     // wave 0: the game's search, wave 1: its helper (encodes the leaf's planes while wave 0 generates the moves); both run
     // inside the tower's prologue (tower_body, Pre), after every wave has requested its first weights
     if (threadIdx.x == 0) s_box.state = 0;   // LDS starts with whatever the previous workgroup left: clear the mailbox ...

@@ -1,3 +1,5 @@
+# developer tool (experiment build, tools/build_exp.sh): where the fused step kernel's expansion spends its cycles, from the kernel's
+# first instruction to the end of dev_expand.   SC_ENGINE_LIB=.../lib_exp/libsc_engine.so python tools/dbg_expand.py
 import ctypes as C, os, sys
 import numpy as np
 ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
@@ -14,10 +16,13 @@ acc = []
 for it in range(20):
     sp.enqueue(3)
     eng.L.sc_engine_synchronize(eng.h)
-    out = np.zeros((G, 16), np.uint64)
+    out = np.zeros((G, 32), np.uint64)
     L.sc_selfplay_debug_cycles(sp.h, 0, out.ctypes.data)
     acc.append(out.astype(np.int64))
 a = np.stack(acc)
-for n, i, j in [("kernel entry -> search starts", 13, 0), ("entry -> loads issued", 0, 8), ("loads issued -> ctl in SGPRs", 8, 9), ("ctl -> value ready", 9, 10), ("value -> children written", 10, 11), ("backward", 11, 12), ("rest of expand", 12, 1), ("whole expand", 0, 1)]:
+for n, i, j in [("kernel entry -> search starts", 21, 0), ("entry -> loads issued", 0, 16), ("loads issued -> ctl in SGPRs", 16, 17), ("ctl -> value ready", 17, 18), ("value -> children written", 18, 19), ("backward", 19, 20), ("rest of expand", 20, 1), ("whole expand", 0, 1)]:
     x = a[..., j] - a[..., i]; x = x[(x > 0) & (x < 10**6)]
+    if x.size == 0:
+        print(f"{n:32s} (no stamps: needs an experiment build, tools/build_exp.sh)")
+        continue
     print(f"{n:32s} median {np.median(x):8.0f}  mean {x.mean():8.0f}  p90 {np.percentile(x, 90):8.0f}")

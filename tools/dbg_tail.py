@@ -17,7 +17,7 @@ acc = []
 for it in range(20):
     sp.enqueue(3)
     eng.L.sc_engine_synchronize(eng.h)
-    out = np.zeros((G, 16), np.uint64)
+    out = np.zeros((G, 32), np.uint64)
     L.sc_selfplay_debug_cycles(sp.h, 0, out.ctypes.data)
     acc.append(out.astype(np.int64))
 a = np.stack(acc)
