@@ -25,6 +25,7 @@
 #include "chess_history.hpp"
 #include "chess_rules_wave.hpp"
 #include "mcts_types.hpp"
+#include "value_tail.hpp"
 
 namespace sc {
 
@@ -86,20 +87,8 @@ __device__ __forceinline__ int wave_argmax_last_lane(float u, bool has) {
     const unsigned long long mask = __ballot(has && k == wm);
     return mask ? 63 - __clzll((long long)mask) : -1;
 }
-// float sum over the wave by DPP (row of 16) + readlanes, in the order of nn_kernels.hpp's wave_sum64 (the fused value
-// tail below and k_value_finish must agree bitwise)
-__device__ __forceinline__ float wave_sum_f_dpp(float v) {
-#pragma clang fp contract(off)   // exact f32 like the reference, in whichever translation unit this is compiled (see wave_sync)
-    auto d = [](float x, auto tag) {
-        return __builtin_bit_cast(float, dpp_i<decltype(tag)::value>(__builtin_bit_cast(int, x)));
-    };
-    v += d(v, std::integral_constant<int, 0xB1>{});
-    v += d(v, std::integral_constant<int, 0x4E>{});
-    v += d(v, std::integral_constant<int, 0x141>{});
-    v += d(v, std::integral_constant<int, 0x140>{});
-    auto rl = [&](int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); };
-    return (rl(0) + rl(16)) + (rl(32) + rl(48));
-}
+// float sum over the wave in the fixed order the value tail uses (value_tail.hpp)
+__device__ __forceinline__ float wave_sum_f_dpp(float v) { return scvt::wave_sum_fixed(v); }
 __device__ inline float wave_sum_f(float v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
@@ -839,20 +828,15 @@ __device__ inline void finish_game(SpParams& p, int g, int lane, int has_outcome
 // no separate launch): + meta columns + bias, ReLU, Linear 128->1, tanh, times (2*turn-1)
 // Two halves: every address depends on the game slot only, so the loads are requested at the very top of the expansion,
 // together with the control block (one round trip earlier than the path statistics, which need the control block).
-struct ValueTail {
-    float2 acc[64];
-    float2 bias, w2, wm[7];
-    int32_t meta[7];
-    float fc2b;
-};
+using scvt::ValueTail;
 __device__ __forceinline__ void value_tail_issue(const SpParams& p, int g, int lane, ValueTail& t) {
     const float* wf = p.vf_w;
     const int32_t* meta = p.meta + (size_t)g * 8;
 #pragma unroll
     for (int k = 0; k < 7; k++) t.meta[k] = meta[k];
     // lane owns output columns 2*lane, 2*lane+1; ALL split-K partials are requested before the first add (one L2
-    // round trip instead of one per 32 partials), then summed in fixed ascending order (same order and column
-    // mapping as k_value_finish: the two paths are bitwise identical)
+    // round trip instead of one per 32 partials), then summed in fixed ascending order by value_tail.hpp's
+    // value_tail_compute -- the function k_value_finish calls too (tests/test_gpu_netloop.py: bitwise identical)
     const int j = 2 * lane;
     const float* vp = p.vpart + (size_t)g * 128 + j;
     const size_t vstride = (size_t)p.n_slots * 128;
@@ -873,41 +857,7 @@ __device__ __forceinline__ void value_tail_issue(const SpParams& p, int g, int l
     for (int k = 0; k < 7; k++) t.wm[k] = *reinterpret_cast<const float2*>(wf + p.vf_fc1m + k * 128 + j);
     t.fc2b = wf[p.vf_fc2b];
 }
-__device__ __forceinline__ float value_tail_finish(const SpParams& p, const ValueTail& t) {
-#pragma clang fp contract(off)   // exact f32 like the reference, in whichever translation unit this is compiled (see wave_sync)
-    float m[7];
-#pragma unroll
-    for (int k = 0; k < 7; k++) {
-        // meta is fed to the net as bf16 (src/backends/torch.rs:120-123)
-        uint32_t u = __builtin_bit_cast(uint32_t, (float)t.meta[k]);
-        u = (u + 0x7fffu + ((u >> 16) & 1u)) & 0xffff0000u;
-        m[k] = __builtin_bit_cast(float, u);
-    }
-    float s0 = t.bias.x, s1 = t.bias.y;
-#pragma unroll
-    for (int ks = 0; ks < 32; ks++) {
-        s0 += t.acc[ks].x;
-        s1 += t.acc[ks].y;
-    }
-    if (p.vf_ksplit > 32) {
-#pragma unroll
-        for (int ks = 32; ks < 64; ks++) {
-            s0 += t.acc[ks].x;
-            s1 += t.acc[ks].y;
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < 7; k++) {
-        s0 += m[k] * t.wm[k].x;
-        s1 += m[k] * t.wm[k].y;
-    }
-    s0 = s0 < 0.f ? 0.f : s0;   // ReLU that keeps a NaN (torch.relu does; `s > 0 ? s : 0` would swallow it)
-    s1 = s1 < 0.f ? 0.f : s1;
-    float part = s0 * t.w2.x + s1 * t.w2.y;
-    part = wave_sum_f_dpp(part);   // same order as k_value_finish (nn_kernels.hpp: wave_sum64)
-    float v = tanhf(part + t.fc2b);
-    return v * (float)(t.meta[0] * 2 - 1);
-}
+__device__ __forceinline__ float value_tail_finish(const SpParams& p, const ValueTail& t) { return scvt::value_tail_compute(t, p.vf_ksplit); }
 
 // cs_out / cs_valid: the control block as this function leaves it, handed to dev_select in registers (a reload would be
 // a load of words stored a few instructions earlier); not valid after a ply transition

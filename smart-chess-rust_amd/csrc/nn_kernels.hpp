@@ -25,6 +25,7 @@
 #include <stdint.h>
 
 #include "nn_types.hpp"
+#include "value_tail.hpp"
 
 namespace scnn {
 
@@ -261,40 +262,35 @@ __global__ __launch_bounds__(256) void k_value_fc1(Fc1Args A) {
     fc1_mma_store(w, s_a, A.vpart, A.n_pos, mb, ks, A.ksplit, wave, lane);
 }
 
-// value head tail (py/module.py:95-106,147-149): + meta columns + bias, ReLU, Linear 128->1, tanh,
-// times (2*turn-1).  One wave per position.
+// value head tail (py/module.py:95-106,147-149), one wave per position: the arithmetic is value_tail.hpp's, shared with the
+// search kernel's fused tail (mcts_kernels.hpp: value_tail_issue / value_tail_finish), so `predict` and the value the
+// search backs up are the same bits.
 __global__ __launch_bounds__(64) void k_value_finish(VfinArgs A) {
     const int pos = blockIdx.x, lane = threadIdx.x;
     if (pos >= A.n_pos) return;
     const float* wf = A.net.wf;
-    float m[7];
+    scvt::ValueTail t;
 #pragma unroll
-    for (int k = 0; k < 7; k++) m[k] = bf2f(f2bf((float)A.meta[(size_t)pos * A.meta_stride + k]));  // meta is fed as bf16 (torch.rs:120-123)
-    // lane owns columns 2*lane, 2*lane+1; partials summed in ascending split order (same arithmetic as the fused
-    // tail in mcts_kernels.hpp value_from_partials)
-    const int j = 2 * lane;
-    const float2 bias = *reinterpret_cast<const float2*>(wf + A.net.f_fc1b + j);
-    float s0 = bias.x, s1 = bias.y;
-    for (int ks = 0; ks < A.ksplit; ks++) {
-        const float2 a = *reinterpret_cast<const float2*>(A.vpart + ((size_t)ks * A.n_pos + pos) * FC1_N + j);
-        s0 += a.x;
-        s1 += a.y;
-    }
+    for (int k = 0; k < 7; k++) t.meta[k] = A.meta[(size_t)pos * A.meta_stride + k];
+    const int j = 2 * lane;   // lane owns output columns 2*lane, 2*lane+1
+    const float* vp = A.vpart + (size_t)pos * FC1_N + j;
+    const size_t vstride = (size_t)A.n_pos * FC1_N;
 #pragma unroll
-    for (int k = 0; k < 7; k++) {
-        const float2 w = *reinterpret_cast<const float2*>(wf + A.net.f_fc1m + k * FC1_N + j);
-        s0 = __fadd_rn(s0, __fmul_rn(m[k], w.x));   // no FMA contraction: the fused tail is built with -ffp-contract=off
-        s1 = __fadd_rn(s1, __fmul_rn(m[k], w.y));
+    for (int ks = 0; ks < 32; ks++) t.acc[ks] = *reinterpret_cast<const float2*>(vp + (size_t)ks * vstride);
+    if (A.ksplit > 32) {
+#pragma unroll
+        for (int ks = 32; ks < 64; ks++) t.acc[ks] = *reinterpret_cast<const float2*>(vp + (size_t)ks * vstride);
+    } else {
+#pragma unroll
+        for (int ks = 32; ks < 64; ks++) t.acc[ks] = make_float2(0.f, 0.f);
     }
-    s0 = s0 < 0.f ? 0.f : s0;   // ReLU that keeps a NaN (torch.relu does; `s > 0 ? s : 0` would swallow it)
-    s1 = s1 < 0.f ? 0.f : s1;
-    const float2 w2 = *reinterpret_cast<const float2*>(wf + A.net.f_fc2w + j);
-    float part = __fadd_rn(__fmul_rn(s0, w2.x), __fmul_rn(s1, w2.y));
-    part = wave_sum64(part);   // same DPP order as the fused tail in the search kernel (mcts_kernels.hpp: wave_sum_f_dpp)
-    if (lane == 0) {
-        float v = tanhf(part + wf[A.net.f_fc2b]);
-        A.value[pos] = v * (float)(A.meta[(size_t)pos * A.meta_stride] * 2 - 1);
-    }
+    t.bias = *reinterpret_cast<const float2*>(wf + A.net.f_fc1b + j);
+    t.w2 = *reinterpret_cast<const float2*>(wf + A.net.f_fc2w + j);
+#pragma unroll
+    for (int k = 0; k < 7; k++) t.wm[k] = *reinterpret_cast<const float2*>(wf + A.net.f_fc1m + k * FC1_N + j);
+    t.fc2b = wf[A.net.f_fc2b];
+    const float v = scvt::value_tail_compute(t, A.ksplit);
+    if (lane == 0) A.value[pos] = v;
 }
 
 #endif  // SC_NO_KERNELS
