@@ -88,12 +88,11 @@ int sc_forward_batch(sc_engine*, int n, const int8_t* boards, const int32_t* met
 int sc_predict_batch(sc_engine*, int n, const int8_t* boards, const int32_t* meta, const uint16_t* legal_idx,
                      const uint32_t* legal_off, float* priors, float* value);
 
-/* Device-resident variant of sc_predict_batch used by the benchmark and by L-search: all
- * pointers are device pointers, move tables have row stride SC_MAX_MOVES, launch is asynchronous
- * on the engine's stream. */
-int sc_predict_batch_device(sc_engine*, int n, const int8_t* d_boards, const int32_t* d_meta,
-                            const uint16_t* d_legal_idx, const int32_t* d_n_legal, float* d_priors, float* d_value,
-                            float* d_logp_or_null);
+/* Game::predict with argmax = true (the reference passes it from chess_play_inference, src/lib.rs:333-337): the same, then
+ * post_process_distr's argmax branch (src/chess.rs:880-889) -- priors become a one-hot vector at the LAST maximum of each
+ * position (Iterator::max_by). */
+int sc_predict_batch_argmax(sc_engine*, int n, const int8_t* boards, const int32_t* meta, const uint16_t* legal_idx,
+                            const uint32_t* legal_off, float* priors, float* value);
 int sc_engine_synchronize(sc_engine*);
 /* test aid: fp32 residual stream [n][64][channels] after `stage` (0 = conv_block, b = res block b, 1000 = trunk output) */
 int sc_forward_debug(sc_engine*, int n, const int8_t* boards, const int32_t* meta, int stage, float* out);

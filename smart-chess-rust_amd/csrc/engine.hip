@@ -29,6 +29,30 @@ static void dfree(std::initializer_list<void*> ptrs) {
         if (q) (void)hipFree(q);
 }
 
+// The C ABI's structs are bound field by field from Rust (integration/hip.rs), ctypes (scamd/binding.py) and C: their layout
+// is part of the interface.  A new field goes at the END, together with the bindings (tests/test_abi.py compares all three).
+#define SC_LAYOUT(T, size) static_assert(sizeof(T) == (size), #T ": size changed -- update integration/hip.rs and scamd/binding.py")
+#define SC_FIELD(T, f, off) static_assert(offsetof(T, f) == (off), #T "." #f ": offset changed")
+SC_LAYOUT(sc_net_config, 24);
+SC_FIELD(sc_net_config, n_res_blocks, 0); SC_FIELD(sc_net_config, channels, 4); SC_FIELD(sc_net_config, seed, 8);
+SC_FIELD(sc_net_config, precision, 16); SC_FIELD(sc_net_config, reserved, 20);
+SC_LAYOUT(sc_selfplay_config, 88);
+SC_FIELD(sc_selfplay_config, n_slots, 0); SC_FIELD(sc_selfplay_config, n_games, 4); SC_FIELD(sc_selfplay_config, rollout_num, 8);
+SC_FIELD(sc_selfplay_config, num_steps, 12); SC_FIELD(sc_selfplay_config, cpuct, 16); SC_FIELD(sc_selfplay_config, temperature, 20);
+SC_FIELD(sc_selfplay_config, temperature_switch, 24); SC_FIELD(sc_selfplay_config, epsilon, 28); SC_FIELD(sc_selfplay_config, with_noise, 32);
+SC_FIELD(sc_selfplay_config, outcome_gate, 36); SC_FIELD(sc_selfplay_config, evaluator, 40); SC_FIELD(sc_selfplay_config, external_noise, 44);
+SC_FIELD(sc_selfplay_config, seed, 48); SC_FIELD(sc_selfplay_config, first_game_id, 56); SC_FIELD(sc_selfplay_config, trace_capacity, 64);
+SC_FIELD(sc_selfplay_config, own_stream, 68); SC_FIELD(sc_selfplay_config, tie_random, 72); SC_FIELD(sc_selfplay_config, trace_hold, 76);
+SC_FIELD(sc_selfplay_config, rollout_factor, 80);
+SC_LAYOUT(sc_selfplay_stats, 32);
+SC_FIELD(sc_selfplay_stats, sims_done, 0); SC_FIELD(sc_selfplay_stats, nn_evals, 8); SC_FIELD(sc_selfplay_stats, games_finished, 16);
+SC_FIELD(sc_selfplay_stats, games_active, 20); SC_FIELD(sc_selfplay_stats, error_flags, 24); SC_FIELD(sc_selfplay_stats, plies_done, 28);
+SC_LAYOUT(sc_trace_info, 32);
+SC_FIELD(sc_trace_info, n_steps, 0); SC_FIELD(sc_trace_info, n_children_total, 4); SC_FIELD(sc_trace_info, has_outcome, 8);
+SC_FIELD(sc_trace_info, termination, 12); SC_FIELD(sc_trace_info, winner, 16); SC_FIELD(sc_trace_info, game_id, 24);
+#undef SC_LAYOUT
+#undef SC_FIELD
+
 static thread_local std::string g_err;
 static thread_local std::string g_warn;
 static int fail(const std::string& m, int code = -1) {
@@ -319,14 +343,22 @@ int sc_predict_batch(sc_engine* e, int n, const int8_t* boards, const int32_t* m
     return 0;
 }
 
-int sc_predict_batch_device(sc_engine* e, int n, const int8_t* d_boards, const int32_t* d_meta, const uint16_t* d_legal_idx,
-                            const int32_t* d_n_legal, float* d_priors, float* d_value, float* d_logp_or_null) {
-    if (!e || n < 0) return fail("bad argument");
-    HIPOK(hipSetDevice(e->device));
-    int rc = engine_reserve(e, n);
+/* Game::predict with argmax = true: post_process_distr's first branch (src/chess.rs:880-889) -- a one-hot vector at the
+ * LAST maximal prior of each position (Iterator::max_by).  The maximum is taken over the renormalised priors: the
+ * reference takes it over exp(logp[idx]) before the division, which orders the moves the same way except where two
+ * different values round to the same quotient. */
+int sc_predict_batch_argmax(sc_engine* e, int n, const int8_t* boards, const int32_t* meta, const uint16_t* legal_idx,
+                            const uint32_t* legal_off, float* priors, float* value) {
+    int rc = sc_predict_batch(e, n, boards, meta, legal_idx, legal_off, priors, value);
     if (rc) return rc;
-    enqueue_forward(e, n, d_boards, d_meta, 7, d_legal_idx, d_n_legal, d_priors, d_value, d_logp_or_null, nullptr, -1, e->stream);
-    HIPOK(hipGetLastError());
+    for (int i = 0; i < n; i++) {
+        const uint32_t a = legal_off[i], b = legal_off[i + 1];
+        if (b == a) continue;
+        uint32_t best = a;
+        for (uint32_t k = a + 1; k < b; k++)
+            if (!(priors[k] < priors[best])) best = k;   // >= : the last maximum; a NaN prior wins like partial_cmp().unwrap() would panic
+        for (uint32_t k = a; k < b; k++) priors[k] = k == best ? 1.0f : 0.0f;
+    }
     return 0;
 }
 

@@ -63,7 +63,7 @@ ABI = {
     "sc_engine_precision": (_i, [_vp]),
     "sc_forward_batch": (_i, [_vp, _i, _vp, _vp, _vp, _vp]),
     "sc_predict_batch": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "sc_predict_batch_device": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "sc_predict_batch_argmax": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sc_engine_synchronize": (_i, [_vp]),
     "sc_forward_debug": (_i, [_vp, _i, _vp, _vp, _i, _vp]),
     "sc_encode_positions": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -183,8 +183,9 @@ class Engine:
         _check(self.L.sc_forward_debug(self.h, n, _p(boards), _p(meta), stage, _p(out)))
         return out
 
-    def predict(self, boards, meta, legal_idx):
-        """Game::predict tail: legal_idx = list (per position) of action indices -> (list of priors, value[n])"""
+    def predict(self, boards, meta, legal_idx, argmax=False):
+        """Game::predict tail: legal_idx = list (per position) of action indices -> (list of priors, value[n]);
+        argmax: post_process_distr's one-hot branch (src/chess.rs:880-889)"""
         boards = np.ascontiguousarray(boards, np.int8).reshape(-1, 8, 8, 112)
         meta = np.ascontiguousarray(meta, np.int32).reshape(-1, 7)
         n = boards.shape[0]
@@ -194,7 +195,8 @@ class Engine:
                                     np.zeros(0, np.uint16), np.uint16)
         pri = np.zeros(int(off[-1]), np.float32)
         value = np.zeros(n, np.float32)
-        _check(self.L.sc_predict_batch(self.h, n, _p(boards), _p(meta), _p(flat), _p(off), _p(pri), _p(value)))
+        fn = self.L.sc_predict_batch_argmax if argmax else self.L.sc_predict_batch
+        _check(fn(self.h, n, _p(boards), _p(meta), _p(flat), _p(off), _p(pri), _p(value)))
         return [pri[off[i]:off[i + 1]] for i in range(n)], value
 
 
@@ -438,13 +440,8 @@ class ChessHip:
         if enc["n_legal"][0] == 0:
             w = enc["winner"][0]
             return [], np.zeros(0, np.float32), (1.0 if w == 1 else -1.0 if w == 0 else 0.0)
-        pri, val = self.engine.predict(enc["boards"], enc["meta"], [enc["legal_idx"][0]])
-        p = pri[0]
-        if argmax:  # post_process_distr argmax branch (src/chess.rs:880-889)
-            o = np.zeros_like(p)
-            o[len(p) - 1 - int(np.argmax(p[::-1]))] = 1.0   # Iterator::max_by keeps the LAST maximum
-            p = o
-        return list(enc["legal_moves"][0]), p, float(val[0])
+        pri, val = self.engine.predict(enc["boards"], enc["meta"], [enc["legal_idx"][0]], argmax=argmax)
+        return list(enc["legal_moves"][0]), pri[0], float(val[0])
 
     @staticmethod
     def reverse_q(moves):

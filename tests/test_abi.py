@@ -123,3 +123,76 @@ def test_move_index_host_function(orc):
             assert scamd.encode_move(st.turn, m) == orc.move_index(m, st.turn)
             n += 1
     assert n > 1000
+
+
+# ---------------------------------------------------------------------------------- struct layouts: header == Rust == ctypes
+_RUST_T = {"i32": ("int32_t", C.c_int32), "u64": ("uint64_t", C.c_uint64), "i64": ("int64_t", C.c_int64), "f32": ("float", C.c_float)}
+_STRUCTS = {"ScNetConfig": ("sc_net_config", "NetConfig"), "ScSelfplayConfig": ("sc_selfplay_config", "SelfplayConfig"),
+            "ScSelfplayStats": ("sc_selfplay_stats", "Stats"), "ScTraceInfo": ("sc_trace_info", "TraceInfo")}
+
+
+def _rust_structs(src):
+    out = {}
+    for name, body in re.findall(r"#\[repr\(C\)\]\s*pub struct (\w+)\s*\{(.*?)\}", src, flags=re.S):
+        body = re.sub(r"//.*", "", body)
+        out[name] = [(f, t) for f, t in re.findall(r"(?:pub\s+)?(\w+)\s*:\s*([\w\[\]; ]+?)\s*,", body)]
+    return out
+
+
+def _c_structs(hdr):
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    out = {}
+    for body, name in re.findall(r"typedef struct\s*\{(.*?)\}\s*(\w+)\s*;", hdr, flags=re.S):
+        out[name] = [(f, t) for t, f in re.findall(r"(\w+)\s+(\w+)\s*;", body)]
+    return out
+
+
+def test_rust_binding_structs_match_the_header(scamd):
+    """integration/hip.rs (the reference-side binding, src/game.rs:3-21's implementor) declares every struct of the ABI with the
+    header's fields -- same names, order and types -- and so does the ctypes binding; sizes and offsets agree with what a C
+    compiler makes of the header (csrc/engine.hip pins those with static_asserts).  VERDICT r02: the documented Rust
+    struct had fallen 8 bytes behind the header."""
+    rs = _rust_structs(open(os.path.join(ROOT, "integration", "hip.rs")).read())
+    cs = _c_structs(open(os.path.join(ROOT, "include", "sc_engine.h")).read())
+    assert set(_STRUCTS.values()) and set(cs) == {v[0] for v in _STRUCTS.values()}, set(cs)
+    for rname, (cname, pyname) in _STRUCTS.items():
+        rfields, cfields = rs[rname], cs[cname]
+        py = getattr(scamd.binding, pyname)
+        assert [f for f, _ in rfields] == [f for f, _ in cfields] == [f for f, _ in py._fields_], rname
+        for (f, rt), (_, ct), (_, pt) in zip(rfields, cfields, py._fields_):
+            assert _RUST_T[rt][0] == ct and _RUST_T[rt][1] is pt, (rname, f, rt, ct, pt)
+        # the C layout rules applied to the Rust field list (repr(C)) give the ctypes size and offsets
+        off = 0
+        for f, rt in rfields:
+            sz = C.sizeof(_RUST_T[rt][1])
+            off = (off + sz - 1) // sz * sz
+            assert getattr(py, f).offset == off, (rname, f)
+            off += sz
+        align = max(C.sizeof(_RUST_T[rt][1]) for _, rt in rfields)
+        assert C.sizeof(py) == (off + align - 1) // align * align, rname
+    assert C.sizeof(scamd.binding.NetConfig) == 24 and C.sizeof(scamd.binding.SelfplayConfig) == 88
+    assert C.sizeof(scamd.binding.Stats) == 32 and C.sizeof(scamd.binding.TraceInfo) == 32
+    # ... and the engine's own static_asserts carry the same numbers
+    eng = open(os.path.join(ROOT, "smart-chess-rust_amd", "csrc", "engine.hip")).read()
+    for cname, size in (("sc_net_config", 24), ("sc_selfplay_config", 88), ("sc_selfplay_stats", 32), ("sc_trace_info", 32)):
+        assert f"SC_LAYOUT({cname}, {size});" in eng
+        for f, _ in cs[cname]:
+            assert re.search(rf"SC_FIELD\({cname}, {f}, \d+\)", eng), (cname, f)
+
+
+def test_rust_binding_functions_are_the_headers(scamd):
+    """every `extern "C"` function integration/hip.rs binds is declared in the header with the same number of parameters"""
+    src = open(os.path.join(ROOT, "integration", "hip.rs")).read()
+    ext = re.search(r'extern "C" \{(.*?)\n\}', src, flags=re.S).group(1)
+    ext = re.sub(r"//.*", "", ext)
+    rust_fns = {n: len([a for a in args.split(",") if a.strip()]) for n, args in re.findall(r"fn (sc_\w+)\((.*?)\)", ext, flags=re.S)}
+    assert {"sc_engine_create", "sc_predict_batch", "sc_predict_batch_argmax", "sc_encode_positions", "sc_selfplay_create"} <= set(rust_fns)
+    hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "sc_engine.h")).read(), flags=re.S)
+    for name, n_args in rust_fns.items():
+        m = re.search(rf"\b{name}\s*\((.*?)\)\s*;", hdr, flags=re.S)
+        assert m, name
+        cargs = [a for a in m.group(1).split(",") if a.strip() and a.strip() != "void"]
+        assert len(cargs) == n_args == len(scamd.binding.ABI[name][1]), (name, len(cargs), n_args)
+    # INTEGRATION.md points at the file instead of carrying a second copy of the structs
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    assert "integration/hip.rs" in doc and "#[repr(C)]" not in doc

@@ -143,6 +143,22 @@ def test_predict_contract(scamd, orc):
     eng.close()
 
 
+def test_predict_argmax_branch(scamd, orc):
+    """Game::predict(argmax = true) through the C ABI (sc_predict_batch_argmax): post_process_distr's first branch
+    (src/chess.rs:880-889) -- one-hot at the LAST maximal prior; the value is unchanged"""
+    eng = scamd.Engine(2, 128, seed=9)
+    hip = scamd.ChessHip(eng)
+    for line in ([], ["e2e4", "c7c5", "g1f3"], ["f2f3", "e7e5", "g2g4"]):
+        steps, pri, val = hip.predict(line)
+        steps2, hot, val2 = hip.predict(line, argmax=True)
+        assert list(steps) == list(steps2) and val == val2
+        want = len(pri) - 1 - int(np.argmax(np.asarray(pri)[::-1]))
+        assert hot.sum() == 1.0 and hot[want] == 1.0 and set(np.unique(hot)) == {0.0, 1.0}
+    steps, hot, val = hip.predict(["f2f3", "e7e5", "g2g4", "d8h4"], argmax=True)   # terminal: nothing to post-process
+    assert steps == [] and len(hot) == 0 and val == -1.0
+    eng.close()
+
+
 # ---------------------------------------------------------------------------------- search (a1-a9, a20)
 def _same_tree(t, d):
     return (len(t["n"]) == len(d["n"]) and np.array_equal(t["n"], d["n"]) and np.array_equal(t["q"], d["q"])
