@@ -12,9 +12,12 @@ self-play games per GPU from the start position, rollout = 180, 10-block ResNet 
 cpuct 2.5, temperature switch 4 (README.md:39 of the reference).  Everything is resident in HBM before the
 timed region; games shard across ranks with no collective on the data path (weak scaling).
 
-Prints ONE JSON line (rank 0) with `roofline` (dominant kernel = the network tower, priced against the
-dense bf16 MFMA peak) and, at N=1, `cpu_baseline` (the CPU oracle = port of the reference algorithm,
-timed on the host cores on a bounded sample).
+Prints ONE JSON line (rank 0) with `roofline` (dominant kernel = the step launch `k_step` -- search wave, network tower
+and value-FC tile of every game in one launch, 96 % of GPU time -- timed with HIP events around sampled launches on the
+launch stream and priced with the FULL forward's FLOP against the dense MFMA peak) and, at N=1, `cpu_baseline` (the CPU
+oracle = port of the reference algorithm, timed on the host cores on a bounded sample).  `also_tower` keeps the tower-only
+figure (separate launches), `phases_us` the split of a step launch, `also_encode_steps` / `also_match` the widened rows
+(SURVEY.md 8f rank 1 and 2).  Exits non-zero when the engine reports error flags.
 """
 import argparse
 import json
@@ -137,6 +140,7 @@ def run_gpu(args, rank, world, local_rank):
                  # BASELINE configs[3]'s per-GPU slice: 20 blocks x 256 channels, rollout 800 (one timed ply)
                  ("deep", 256, args.games, 1)]
     for tag, C, G, K in runs:
+        progress(f"run {tag}: {G} games, {K} group(s)")
         prec = "fp8" if tag.startswith("fp8") else args.precision
         R = 800 if tag == "deep" else args.rollout
         blocks = 20 if tag == "deep" else args.blocks
@@ -168,7 +172,7 @@ def run_gpu(args, rank, world, local_rank):
             seed_mid_game_positions(scamd, eng, sps[0], G, R)
         enqueue((1 if tag == "deep" else args.warmup) * R)
         for sp in sps:
-            sp.enable_timing(args.timing_stride)
+            sp.enable_timing(-args.timing_stride)   # every n-th step launch bracketed as a whole, launch form unchanged
             sp.timing(reset=True)
         # `repeats` timed regions of exactly `steps` plies each, every one bracketed by barrier + synchronise on both sides;
         # the reported region is the median one (median of 3)
@@ -195,18 +199,108 @@ def run_gpu(args, rank, world, local_rank):
         nl = sum(t["tower_launches"] for t in tms)
         res[tag] = dict(C=C, precision=prec, regions=regions, steps=steps, blocks=blocks, rollout=R, nn_evals=s1["nn_evals"] - nn0["nn_evals"],
                         sims_all=s1["sims_done"] - nn0["sims_done"], err=s1["error_flags"],
-                        tower_ms=sum(t["ms_tower_sum"] for t in tms) / max(nl, 1), tower_launches=nl,
-                        span_ms=max(t["ms_total"] for t in tms), groups=K, games=G)
+                        step_ms=sum(t["ms_tower_sum"] for t in tms) / max(nl, 1), steps_timed=nl,
+                        span_ms=max(t["ms_total"] for t in tms), groups=K, games=G, launches_per_step=sps[0].launches_per_step())
+        if tag == "main" and K == 1:
+            progress("phase stamps")
+            res[tag]["phases_us"] = step_phases(sps[0], R)
+            progress("tower-only sample")
+            # the tower launch alone: a few plies with every 4th step as separate launches, the tower bracketed by events
+            sps[0].enable_timing(4)
+            sps[0].timing(reset=True)
+            enqueue(2 * R)
+            tt = sps[0].timing()
+            res[tag]["tower_ms"] = tt["ms_tower_sum"] / max(tt["tower_launches"], 1)
+            res[tag]["tower_launches"] = tt["tower_launches"]
+            res[tag]["err"] |= stats()["error_flags"]
         if tag == "steady":
             plies = [sps[0].slot(g)["ply"] for g in range(0, G, 8)]
             res[tag]["ply_min_max"] = (min(plies), max(plies))
         if tag in ("main", "sharp", "steady"):   # tree levels walked by the last descent of a sample of games
             lens = [len(sps[0].slot(g)["path"]) for g in range(0, G, 4)]
             res[tag]["mean_path_len"] = sum(lens) / len(lens)
+        if tag == "main" and args.alt and world == 1:
+            progress("encode_steps")
+            res["encode_steps"] = encode_steps_rate(scamd, eng, local_rank)
         for sp in sps:
             sp.close()
         eng.close()
+    if args.alt and world == 1:
+        progress("match")
+        res["match"] = match_rate(scamd, args.blocks, args.channels, local_rank)
     return res
+
+
+def step_phases(sp, R):
+    """per-phase split of the one-launch step from the kernel's own wall-clock stamps (100 MHz; csrc/step_kernels.hip
+    PHASE_STAMP): medians over the workgroups of several launches, microseconds"""
+    import numpy as np
+    if sp.launches_per_step() != 1:
+        return None
+    sp.debug_cycles(True)
+    acc = []
+    for _ in range(12):
+        sp.enqueue(7)
+        a = sp.debug_cycles(True, read=True).astype(np.int64)   # (plain stream sync: the stamps of the last step launch)
+        acc.append(a[:, 24:28])
+    a = np.concatenate(acc)
+    a = a[(a[:, 1] > a[:, 0]) & (a[:, 2] > a[:, 1]) & (a[:, 3] >= a[:, 2])]    # workgroups that ran all phases
+    if len(a) == 0:
+        return None
+    us = lambda x: round(float(np.median(x)) / 100.0, 2)
+    return {"search": us(a[:, 1] - a[:, 0]), "tower": us(a[:, 2] - a[:, 1]), "value_fc_tile": us(a[:, 3] - a[:, 2]),
+            "workgroup_total": us(a[:, 3] - a[:, 0]), "workgroups_sampled": int(len(a)),
+            "note": "medians over workgroups of 12 step launches: kernel entry -> leaf selected (expand + backup of the previous simulation, "
+                    "descent, move generation, plane encoding) -> network done -> value_head.ffn.0 tile done; the launch also pays its ramp "
+                    "and the slowest workgroup"}
+
+
+def encode_steps_rate(scamd, eng, device):
+    """SURVEY.md 8f rank 1 (libsmartchess.chess_encode_steps, reference src/lib.rs:46-128): traces of 256 quick self-play games
+    -> training tensors through sc_encode_steps.  The ABI hands over host buffers, so the call includes the PCIe copy-out of
+    26.3 KB per ply; the kernels' own time (HIP events) prices the HBM write rate."""
+    quick = scamd.SelfPlay(eng, n_slots=256, n_games=256, rollout_num=8, num_steps=100, cpuct=2.5, temperature=0.0, temperature_switch=8,
+                           epsilon=0.15, with_noise=True, seed=5, outcome_gate=10 ** 6, device=device)
+    quick.run()
+    games = []
+    for g in range(256):
+        tr = quick.trace(g)
+        games.append([(s[0], [(c[0], c[1]) for c in s[2]]) for s in tr["steps"]])
+    quick.close()
+    scamd.encode_steps_batch(games[:8], device=device, engine=eng)   # warm-up (allocations, first launch)
+    t0 = time.perf_counter()
+    r = scamd.encode_steps_batch(games, device=device, engine=eng)
+    wall = time.perf_counter() - t0
+    k_ms, call_ms = scamd.binding.encode_steps_last_timing()
+    plies = int(r["ply_off"][-1])
+    assert int((r["status"] != 0).sum()) == 0
+    out_bytes = plies * (7168 + 28 + 4672 * 4 + 224 * 2 + 4)
+    return {"plies": plies, "games": len(games), "plies_per_s": round(plies / (call_ms * 1e-3), 1), "call_ms": round(call_ms, 2),
+            "kernels_ms": round(k_ms, 3), "python_wall_ms": round(wall * 1e3, 2), "kernels_plies_per_s": round(plies / (k_ms * 1e-3), 1),
+            "bytes_written_per_ply": out_bytes // plies,
+            "roofline": {"bound": "hbm", "achieved": round(out_bytes / (k_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(out_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "kernel": "k_encode_positions + k_steps_dist",
+                         "note": "algorithmic bytes written (planes 7168 + meta 28 + dist 18688 + move indices 448 + count 4 per ply) / HIP-event "
+                                 "time of the two kernels"},
+            "pcie_share_of_call": round(1.0 - k_ms / call_ms, 4),
+            "note": "host-pointer ABI: the call = H2D of the traces + kernels + D2H of the tensors (pageable host memory) + host bookkeeping"}
+
+
+def match_rate(scamd, blocks, C, device):
+    """SURVEY.md 8f rank 2 (`play`, reference src/play.rs:318-343; scripts/leader-board): 100 games between two 10x128 networks,
+    one colour assignment, rollout 100, noise off, outcome after every ply, at most 200 plies"""
+    a, b = scamd.Engine(blocks, C, seed=1, device=device), scamd.Engine(blocks, C, seed=2, device=device)
+    t0 = time.perf_counter()
+    r = scamd.play_match(a, b, n_games=100, rollout=100, cpuct=1.5, temperature=0.0, temperature_switch=0, num_steps=200, seed=3, swap=False)
+    wall = time.perf_counter() - t0
+    res = r["as_white"]["results"]
+    plies = sum(len(t["steps"]) for t in r["as_white"]["traces"] if t)
+    a.close()
+    b.close()
+    return {"games": 100, "rollout": 100, "nets": f"two {blocks}x{C} bf16 (seeds 1, 2)", "wall_s": round(wall, 3), "games_per_s": round(100 / wall, 2),
+            "plies": plies, "simulations_per_s": round(plies * 100 / wall, 1), "results": res,
+            "note": "all 100 games of one colour assignment in lockstep on one handle (sc_selfplay_set_players); games end at different "
+                    "plies, so late plies run with few live games"}
 
 
 def sharp_prior_engine(scamd, n_blocks, C, device, precision):
@@ -244,6 +338,12 @@ def seed_mid_game_positions(scamd, eng, sp, G, R):
 _dist = None
 
 
+def progress(msg):
+    """stderr only (stdout carries the one JSON line); rank 0"""
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
 def barrier():
     if _dist is not None:
         _dist.barrier()
@@ -272,9 +372,9 @@ def main():
     ap.add_argument("--no-alt", dest="alt", action="store_false", help="skip the short extra runs (steady state, other width, 2x games, fp8)")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp8"], help="network precision of the main run (BASELINE configs[1]: bf16)")
     ap.add_argument("--groups", type=int, default=1, help="split the games of a GPU into K groups on K HIP streams (overlap)")
-    ap.add_argument("--timing-stride", type=int, default=32,
-                    help="every n-th simulation step runs as separate launches with the tower bracketed by a HIP event pair for the "
-                         "roofline figure (the other steps are ONE launch, the fused step kernel; a timed step is ~8 us slower)")
+    ap.add_argument("--timing-stride", type=int, default=8,
+                    help="every n-th simulation step's launch(es) are bracketed by a HIP event pair on the launch stream for the roofline "
+                         "figure (the launch form is not changed)")
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU work for cpu_baseline (0 = skip)")
     ap.add_argument("--cpu-dry-run", action="store_true",
                     help="HARNESS TEST ONLY (gloo, no GPU): exercises sharding/timing/aggregation with the oracle's "
@@ -328,7 +428,7 @@ def main():
             barrier()
             regions.append((t1 - t0, sims))
         res = {"main": dict(C=args.channels, regions=regions, steps=args.steps, nn_evals=0, sims_all=sum(r[1] for r in regions), err=0,
-                            tower_ms=0.0, tower_launches=0, span_ms=0.0)}
+                            step_ms=0.0, steps_timed=0, span_ms=0.0)}
     else:
         res = run_gpu(args, rank, world, local_rank)
 
@@ -381,19 +481,34 @@ def main():
         }
         if not args.cpu_dry_run:
             pos_per_launch = args.games // m.get("groups", 1)
-            tf = pos_per_launch * flop_tower / (m["tower_ms"] * 1e-3) / 1e12 if m["tower_ms"] > 0 else 0.0
             peak = PEAK_FP8_TFLOPS if m.get("precision") == "fp8" else PEAK_BF16_TFLOPS
+            prec = m.get("precision", "bf16")
+            form = {1: f"k_step<{prec}, {m['C']}>", 2: f"k_step<{prec}, {m['C']}> + k_value_fc1", 3: "k_mcts + k_tower32 + k_value_fc1"}[m["launches_per_step"]]
+            tf = pos_per_launch * flop_pos / (m["step_ms"] * 1e-3) / 1e12 if m["step_ms"] > 0 else 0.0
             out["roofline"] = {
-                "bound": "mfma", "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s",
-                "frac": round(tf / peak, 4), "traffic": load_traffic(m["C"], m.get("precision", "bf16")),
-                "kernel": f"k_tower32<{m.get('precision', 'bf16')}, {m['C']}>", "avg_launch_ms": round(m["tower_ms"], 4), "launches_timed": m["tower_launches"],
-                "flop_per_launch": pos_per_launch * flop_tower, "positions_per_launch": pos_per_launch, "concurrent_groups": m.get("groups", 1),
+                "bound": "mfma", "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4),
+                "traffic": load_traffic(m["C"], prec, m["launches_per_step"]),
+                "kernel": form, "avg_launch_ms": round(m["step_ms"], 4), "launches_timed": m["steps_timed"],
+                "flop_per_launch": pos_per_launch * flop_pos, "positions_per_launch": pos_per_launch, "concurrent_groups": m.get("groups", 1),
+                "launches_per_step": m["launches_per_step"],
+                "algorithmic_bytes_per_launch": algorithmic_bytes(args.blocks, m["C"], prec, pos_per_launch),
+                "flop_note": "2 x MACs of one whole forward (stem, blocks, both heads incl. value_head.ffn: SURVEY.md 8d) per game and launch; "
+                             "the launch also runs every game's search step (expand + backup, PUCT descent, move generation, plane encoding), "
+                             "which is not matrix work and is priced as zero FLOP",
+                "timing_note": f"HIP events on the launch stream around every {args.timing_stride}th step launch of the timed regions",
                 "chip_sustains_note": "a register-resident loop of independent bf16 32x32x16 MFMAs with non-zero operands holds 1989 TFLOP/s "
-                                      "(0.80 of peak) at this pool's 1400 W cap; this run draws ~1300 W (profiles/r02_exp_power_and_clock.txt)",
-                "flop_note": "the tower launch's own layers (stem, blocks, head convs) on the timed (separately launched) steps; value_head.ffn "
-                             "runs in k_value_fc1 / the search kernel there, inside the fused step kernel on the other steps",
+                                      "(0.80 of peak) at this pool's 1400 W cap (profiles/r02_exp_power_and_clock.txt)",
                 "end_to_end_frac": round(sims / seconds / world * flop_pos / (peak * 1e12), 4),
             }
+            if m.get("phases_us"):
+                out["roofline"]["phases_us"] = m["phases_us"]
+            if m.get("tower_ms"):
+                tft = pos_per_launch * flop_tower / (m["tower_ms"] * 1e-3) / 1e12
+                out["also_tower"] = {"kernel": f"k_tower32<{prec}, {m['C']}>", "avg_launch_ms": round(m["tower_ms"], 4), "launches_timed": m["tower_launches"],
+                                     "achieved": round(tft, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tft / peak, 4),
+                                     "flop_per_launch": pos_per_launch * flop_tower, "traffic": load_traffic(m["C"], prec, 0),
+                                     "note": "the network tower as its own launch (stem, blocks, head convs; no value_head.ffn, no search): production "
+                                             "runs it only inside k_step -- sampled here on separately launched steps after the timed regions"}
             out["nn_evals_per_sim"] = round(m["nn_evals"] / max(m["sims_all"], 1), 4)
             out["error_flags"] = m["err"]
             if "steady" in res:
@@ -410,52 +525,62 @@ def main():
                                             "mean_path_len_main": round(m.get("mean_path_len", 0.0), 2), "error_flags": st["err"],
                                             "note": ("same network with the policy head's last LayerNorm gain x 8 (priors concentrated like a trained "
                                                      "net's): deeper descents, same network cost")}
+
+            def step_frac(x, pk):
+                f = 2.0 * macs_per_position(x["blocks"], x["C"])
+                return round(x["games"] // x["groups"] * f / (x["step_ms"] * 1e-3) / 1e12 / pk, 4) if x["step_ms"] > 0 else None
             if "alt" in res:
                 a = res["alt"]
-                fa = 2.0 * macs_per_position(args.blocks, a["C"], tower_only=True)
                 v, ms = rate(a)
-                out["also"] = {"net": f"{args.blocks}x{a['C']}", "value": round(v, 1), "ms_per_step": round(ms, 3),
-                               "tower_avg_ms": round(a["tower_ms"], 4),
-                               "roofline_frac": round(args.games * fa / (a["tower_ms"] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4)
-                               if a["tower_ms"] > 0 else None}
+                out["also"] = {"net": f"{args.blocks}x{a['C']}", "value": round(v, 1), "ms_per_step": round(ms, 3), "error_flags": a["err"],
+                               "step_avg_ms": round(a["step_ms"], 4), "launches_per_step": a["launches_per_step"],
+                               "roofline_frac": step_frac(a, PEAK_BF16_TFLOPS)}
             if "deep" in res:
                 x = res["deep"]
-                fd = 2.0 * macs_per_position(x["blocks"], x["C"], tower_only=True)
                 v, ms = rate(x)
                 out["also_deep"] = {"config": "BASELINE configs[3], one GPU's slice: 20 blocks x 256 channels bf16, rollout 800, "
                                               f"{x['games']} concurrent games (one timed ply)",
                                     "net": f"{x['blocks']}x{x['C']}", "rollout": x["rollout"], "value": round(v, 1), "ms_per_step": round(ms, 3),
-                                    "tower_avg_ms": round(x["tower_ms"], 4), "error_flags": x["err"],
-                                    "roofline_frac": round(x["games"] * fd / (x["tower_ms"] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4)
-                                    if x["tower_ms"] > 0 else None}
+                                    "step_avg_ms": round(x["step_ms"], 4), "launches_per_step": x["launches_per_step"], "error_flags": x["err"],
+                                    "roofline_frac": step_frac(x, PEAK_BF16_TFLOPS)}
             for tag in ("fp8", "fp8_512"):
                 if tag in res:
                     x = res[tag]
                     v, ms = rate(x)
-                    f8 = 2.0 * macs_per_position(args.blocks, x["C"], tower_only=True)
-                    tf8 = x["games"] * f8 / (x["tower_ms"] * 1e-3) / 1e12 if x["tower_ms"] > 0 else 0.0
+                    f8 = 2.0 * macs_per_position(args.blocks, x["C"])
+                    tf8 = x["games"] * f8 / (x["step_ms"] * 1e-3) / 1e12 if x["step_ms"] > 0 else 0.0
                     out["also_" + tag] = {
                         "config": ("BASELINE configs[4] sizing: fp8 (OCP e4m3) policy/value net on the CDNA4 fp8 matrix cores, "
                                    f"{x['games']} concurrent games per GPU" + ("" if tag == "fp8_512" else " (the headline's game count)")),
                         "dtype": "fp8", "games_per_gpu": x["games"], "net": f"{args.blocks}x{x['C']}", "value": round(v, 1), "ms_per_step": round(ms, 3),
                         "error_flags": x["err"],
                         "roofline": {"bound": "mfma", "achieved": round(tf8, 2), "peak": PEAK_FP8_TFLOPS, "unit": "TFLOP/s",
-                                     "frac": round(tf8 / PEAK_FP8_TFLOPS, 4), "kernel": f"k_tower32<fp8, {x['C']}>",
-                                     "avg_launch_ms": round(x["tower_ms"], 4), "launches_timed": x["tower_launches"],
+                                     "frac": round(tf8 / PEAK_FP8_TFLOPS, 4), "kernel": f"k_step<fp8, {x['C']}>",
+                                     "avg_launch_ms": round(x["step_ms"], 4), "launches_timed": x["steps_timed"], "launches_per_step": x["launches_per_step"],
                                      "flop_per_launch": x["games"] * f8, "positions_per_launch": x["games"],
-                                     "end_to_end_frac": round(v * 2.0 * macs_per_position(args.blocks, x["C"]) / (PEAK_FP8_TFLOPS * 1e12), 4)}}
+                                     "traffic": load_traffic(x["C"], "fp8", x["launches_per_step"], x["games"]),
+                                     "end_to_end_frac": round(v * f8 / (PEAK_FP8_TFLOPS * 1e12), 4)}}
             if "x2" in res:
                 x = res["x2"]
                 v, ms = rate(x)
                 out["also_2x_games"] = {"games_per_gpu": x["games"], "groups": x["groups"], "net": f"{args.blocks}x{x['C']}",
-                                        "value": round(v, 1), "ms_per_step": round(ms, 3),
+                                        "value": round(v, 1), "ms_per_step": round(ms, 3), "error_flags": x["err"],
                                         "note": "two interleaved groups of games on two HIP streams; not the BASELINE configuration"}
+            if "encode_steps" in res:
+                out["also_encode_steps"] = res["encode_steps"]
+            if "match" in res:
+                out["also_match"] = res["match"]
             if world == 1 and args.cpu_budget > 0:
+                progress("cpu_baseline")
                 out["cpu_baseline"] = cpu_baseline(args.blocks, m["C"], args.cpu_budget, args.rollout)
         print(json.dumps(out), flush=True)
     if _dist is not None:
         _dist.barrier()
         _dist.destroy_process_group()
+    # invalid games must not pass for a measurement (include/sc_engine.h: sc_selfplay_stats.error_flags)
+    bad = sorted(k for k, v in res.items() if isinstance(v, dict) and v.get("err"))
+    if bad:
+        raise SystemExit(f"error flags set in run(s) {bad}: the numbers above are not valid")
 
 
 def config_name(args, m):
@@ -470,13 +595,33 @@ def config_name(args, m):
     return "custom configuration"
 
 
-def load_traffic(C, precision="bf16"):
-    """HBM bytes per tower launch from the rocprofv3 PMC passes committed under profiles/ (null if not collected)"""
+def load_traffic(C, precision="bf16", launches_per_step=1, games=256):
+    """HBM-side bytes per launch from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE / WRITE_SIZE, corrected as
+    MI355X_MICROARCH.md prescribes: tools/profile_summarize.py); null if that configuration was not collected.
+    launches_per_step 0 = the stand-alone tower launch."""
     p = os.path.join(ROOT, "profiles", "traffic.json")
+    if launches_per_step == 0:
+        key = f"k_tower32<{C}>" if precision == "bf16" else f"k_tower32<{precision},{C}>"
+    else:
+        key = f"k_step<{precision},{C}>" + ("+fc1" if launches_per_step == 1 else "") + (f"@{games}" if games != 256 else "")
     try:
-        return json.load(open(p)).get(f"k_tower32<{C}>" if precision == "bf16" else f"k_tower32<{precision},{C}>")
+        return json.load(open(p)).get(key)
     except Exception:
         return None
+
+
+def algorithmic_bytes(n_blocks, C, precision, positions):
+    """HBM bytes one step launch HAS to move: the weights once (conv operands at 2 or 1 B per element, SE and value FC
+    bf16, parameters fp32) + ~20 KB per simulation for the search (tree statistics, position records, NN input, priors).  What the
+    launch moves on top of that -- value-head feature rows and split-K partials written and read back (128 KB per position), one copy
+    of the weights per XCD L2 -- is the implementation's own traffic: `roofline.traffic` minus this figure."""
+    wb = 2 if precision == "bf16" else 1
+    H = 256
+    convs = 112 * 9 * C + n_blocks * 2 * 9 * C * C + C * H + C * H + H * 73
+    se = n_blocks * 2 * C * (C // 2)
+    fc = (64 * H + 7) * 128 + 128
+    params = 4 * (8 * C * n_blocks + 8 * C + 6 * H + 2 * 73 + 256)
+    return int(convs * wb + (se + fc) * 2 + params + positions * 20 * 1024)
 
 
 if __name__ == "__main__":

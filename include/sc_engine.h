@@ -40,6 +40,14 @@ typedef struct sc_engine sc_engine;
 typedef struct sc_selfplay sc_selfplay;
 
 const char* sc_last_error(void);
+/* Return codes (every entry point: 0 = ok, or a small positive "not yet / not there" code where its comment says so):
+ *   -1 bad argument or request, -2 HIP runtime error, -3 no GPU (there is no CPU fallback),
+ *   SC_ERR_HANDOFF: the self-play handle is POISONED -- an internal hand-off of one of its step launches timed out
+ *   (sc_selfplay_stats.error_flags & 48), so values were computed from stale data and its trees / traces are invalid.  Once the
+ *   host has seen that (any synchronising call), sc_selfplay_enqueue_sims / _enqueue_interleaved / _run / _synchronize / _poll /
+ *   _get_trace / _write_trace_json refuse with this code; sc_selfplay_get_stats still answers (the flags).  Destroy the handle;
+ *   handles created afterwards on that device use the two-launch step, which has no hand-off between workgroups. */
+#define SC_ERR_HANDOFF (-5)
 int sc_device_count(void);
 /* Launch-path state of the HIP runtime in this process, bit mask.  The engine's three launches per simulation step are
  * ~6 % faster with kernel arguments in device memory (HIP_FORCE_DEV_KERNARG=1), which the HIP runtime reads ONCE, when
@@ -127,6 +135,10 @@ int sc_encode_steps(sc_engine* engine_or_null, int device_id, int n_games, const
                     const uint16_t* child_mv, const uint32_t* child_n, const uint32_t* child_off, int apply_mirror,
                     int8_t* boards, int32_t* meta, float* dist, uint16_t* legal_idx, int32_t* n_legal, int32_t* status);
 
+/* measurement aid (bench.py also_encode_steps): the last sc_encode_steps call of the calling thread -- HIP-event time of its
+ * kernels (k_encode_positions + k_steps_dist, all chunks) and wall time of the whole call including the PCIe copies */
+int sc_encode_steps_last_timing(float* kernels_ms, float* total_ms);
+
 /* ------------------------------------------------------------------ self-play (L-search) */
 /* SYNTH: integer-hash evaluator for exact search-parity tests; SYNTH_COARSE: the same with 2-bit priors and values from
  * {-0.5, 0, 0.5} (exact PUCT ties between some siblings); SYNTH_UNIFORM: uniform priors, value 0 (every unvisited sibling
@@ -187,10 +199,14 @@ typedef struct {
     int32_t plies_done;      /* total plies played over all games */
 } sc_selfplay_stats;
 int sc_selfplay_get_stats(sc_selfplay*, sc_selfplay_stats* out);
-/* HIP-event timing on the stream the kernels are launched on.  enable_timing(stride>0): every
- * stride-th launch of the dominant kernel (the network tower) is bracketed by an event pair.
- * timing(): ms_total = first enqueue -> last enqueue span; ms_nn = sum over the nn_launches sampled
- * tower launches (at most the last 4096). */
+/* HIP-event timing on the stream the kernels are launched on.
+ * enable_timing(stride > 0): every stride-th simulation step runs as three separate launches with the network TOWER launch
+ *   bracketed by an event pair (the tower-only figure).
+ * enable_timing(stride < 0): every |stride|-th simulation step is bracketed AS A WHOLE by an event pair, in whatever launch form
+ *   the handle uses (one k_step launch in the production form): the duration of the dominant kernel as production runs it.
+ * enable_timing(0): off.
+ * timing(): ms_total = first enqueue -> last enqueue span; ms_nn = sum over the nn_launches sampled brackets (at most the last
+ * 4096). */
 int sc_selfplay_enable_timing(sc_selfplay*, int stride);
 /* Match play (the `play` binary's loop, src/play.rs:318-343; batched: every slot is one game of the same pairing).
  * After this call the handle alternates players by ply: even plies are searched with `white`, odd plies with `black`
@@ -258,11 +274,15 @@ int sc_search(sc_engine*, const uint16_t* moves, int n_moves, int rollout, float
 int sc_debug_find_max(int device_id, const float* values, int n, int32_t* out2);
 /* test aid: makes the NEXT one-launch steps of the handle wait for arrivals that never come (the in-launch hand-off's target is
  * raised by `missing` arrivals per block), to show on hardware that the wait is bounded: every workgroup gives up after ~0.2 s,
- * the launch ends and error_flags carries bit 32.  The handle's results are invalid afterwards.  No effect (returns 1) on a
- * handle that does not use the one-launch form. */
+ * the launch ends and error_flags carries bit 32.  The handle's results are invalid afterwards and it refuses further work
+ * (SC_ERR_HANDOFF).  No effect (returns 1) on a handle that does not use the one-launch form. */
 int sc_selfplay_debug_break_handoff(sc_selfplay*, int missing);
-/* developer aid: stamps of the last launch, out[n_slots][32]: 0..7 the search's cycle stamps (tools/dbg_cycles.py), 8.. written
- * by experiment builds only (tools/dbg_tail.py, tools/dbg_expand.py) */
+/* test aid: forget that an in-launch hand-off has failed on the device (after such a failure new handles get the two-launch
+ * step for the rest of the process; tests that provoke the failure restore the default with this).  0 = a record was cleared. */
+int sc_debug_clear_handoff_failure(int device_id);
+/* developer aid: stamps of the last launch, out[n_slots][32]: 0..7 the search's cycle stamps (tools/dbg_cycles.py); 24..27 the
+ * one-launch step's phases on the 100 MHz wall clock (kernel entry, leaf selected, network done, value-FC tile done: bench.py's
+ * per-phase split); the rest written by experiment builds only (tools/dbg_tail.py, tools/dbg_expand.py) */
 int sc_selfplay_debug_cycles(sc_selfplay*, int enable, unsigned long long* out);
 
 /* utility: trace-file JSON writer on caller-provided arrays (no GPU needed) */

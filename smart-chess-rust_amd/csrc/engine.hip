@@ -11,6 +11,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <map>
 #include <mutex>
 #include <string>
@@ -54,6 +55,7 @@ SC_FIELD(sc_trace_info, termination, 12); SC_FIELD(sc_trace_info, winner, 16); S
 #undef SC_FIELD
 
 static thread_local std::string g_err;
+static thread_local float g_encode_ms[2] = {0.f, 0.f};   // last sc_encode_steps of this thread: kernels (HIP events), whole call
 static thread_local std::string g_warn;
 static int fail(const std::string& m, int code = -1) {
     g_err = m;
@@ -440,6 +442,7 @@ int sc_encode_steps(sc_engine* e, int device_id, int n_games, const uint16_t* mo
                     int32_t* meta, float* dist, uint16_t* legal_idx, int32_t* n_legal, int32_t* status) {
     if (n_games < 0 || !move_off || !child_off || !status) return fail("bad argument");
     if (n_games == 0) return 0;
+    const auto t_call = std::chrono::steady_clock::now();
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail("no HIP device available: libsc_engine has no CPU fallback", -3);
     HIPOK(hipSetDevice(e ? e->device : device_id));
@@ -494,6 +497,10 @@ int sc_encode_steps(sc_engine* e, int device_id, int n_games, const uint16_t* mo
     }
     std::vector<int32_t> flags(cap), replay(4 * (size_t)cap);
     std::vector<uint32_t> coff(cap + 1);
+    hipEvent_t evk[2] = {nullptr, nullptr};
+    HIPOK(hipEventCreate(&evk[0]));
+    HIPOK(hipEventCreate(&evk[1]));
+    float kernels_ms = 0.f;
     for (uint32_t p0 = 0; p0 < total; p0 += CH) {
         const uint32_t n = std::min(CH, total - p0);
         for (uint32_t i = 0; i <= n; i++) coff[i] = child_off[p0 + i];   // absolute offsets into d_cmv / d_cn
@@ -501,11 +508,18 @@ int sc_encode_steps(sc_engine* e, int device_id, int n_games, const uint16_t* mo
         HIPOK(hipMemcpy(d_start, pstart.data() + p0, (size_t)n * 4, hipMemcpyHostToDevice));
         HIPOK(hipMemcpy(d_len, plen.data() + p0, (size_t)n * 4, hipMemcpyHostToDevice));
         HIPOK(hipMemset(d_li, 0, (size_t)n * 224 * 2));
+        HIPOK(hipEventRecord(evk[0], nullptr));
         scl::encode_positions((int)n, d_moves, d_start, d_len, d_hist, hist_cap, d_boards, d_meta, d_lm, d_li, d_nl, d_out, nullptr);
         // the ply's own move is moves[start + len] = d_moves + p0 + i
         scl::steps_dist((int)n, d_lm, d_nl, d_moves + p0, d_cmv, d_cn, d_coff, apply_mirror, d_meta, d_dist, d_flags, nullptr);
+        HIPOK(hipEventRecord(evk[1], nullptr));
         HIPOK(hipGetLastError());
         HIPOK(hipDeviceSynchronize());
+        {
+            float ms = 0.f;
+            HIPOK(hipEventElapsedTime(&ms, evk[0], evk[1]));
+            kernels_ms += ms;
+        }
         if (boards) HIPOK(hipMemcpy(boards + (size_t)p0 * 7168, d_boards, (size_t)n * 7168, hipMemcpyDeviceToHost));
         if (meta) HIPOK(hipMemcpy(meta + (size_t)p0 * 7, d_meta, (size_t)n * 28, hipMemcpyDeviceToHost));
         if (dist) HIPOK(hipMemcpy(dist + (size_t)p0 * 4672, d_dist, (size_t)n * 4672 * 4, hipMemcpyDeviceToHost));
@@ -523,6 +537,16 @@ int sc_encode_steps(sc_engine* e, int device_id, int n_games, const uint16_t* mo
     }
     dfree({d_moves, d_cmv, d_cn, d_coff, d_start, d_len, d_hist});
     dfree({d_boards, d_meta, d_nl, d_flags, d_out, d_lm, d_li, d_dist});
+    (void)hipEventDestroy(evk[0]);
+    (void)hipEventDestroy(evk[1]);
+    g_encode_ms[0] = kernels_ms;
+    g_encode_ms[1] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_call).count();
+    return 0;
+}
+
+int sc_encode_steps_last_timing(float* kernels_ms, float* total_ms) {
+    if (kernels_ms) *kernels_ms = g_encode_ms[0];
+    if (total_ms) *total_ms = g_encode_ms[1];
     return 0;
 }
 
@@ -539,8 +563,13 @@ int sc_encode_steps(sc_engine* e, int device_id, int n_games, const uint16_t* mo
 // is the deployment this library is written for.)
 static std::mutex g_fc1_mu;
 static std::map<int, std::pair<hipStream_t, int>> g_fc1_stream;   // device -> (stream, live handles)
+// A device on which an in-launch hand-off has timed out once (the workgroups of a launch were not all resident: someone else
+// is using the GPU) is not trusted with that form again by this process: handles created afterwards use the two-launch form,
+// whose launches do not wait for each other.
+static std::map<int, bool> g_fc1_failed;
 static bool fc1_stream_acquire(int device, hipStream_t s) {
     std::lock_guard<std::mutex> lk(g_fc1_mu);
+    if (g_fc1_failed.count(device)) return false;
     auto it = g_fc1_stream.find(device);
     if (it == g_fc1_stream.end() || it->second.second == 0) {
         g_fc1_stream[device] = {s, 1};
@@ -566,7 +595,8 @@ struct sc_selfplay {
     std::vector<void*> allocs;
     int64_t sim_steps_enqueued = 0;
     // timing
-    int timing_stride = 0;
+    int timing_stride = 0;       // > 0: every n-th step runs as separate launches with the TOWER bracketed by an event pair
+    int step_stride = 0;         // > 0: every n-th step is bracketed as a whole, in the handle's own launch form
     std::vector<hipEvent_t> ev;  // pairs
     int ev_next = 0;
     int64_t ev_recorded = 0;
@@ -593,7 +623,29 @@ struct sc_selfplay {
     uint32_t* d_fc1_ctr = nullptr;   // its arrival counters, one per 64-position block, 128 B apart (monotonic)
     uint32_t fc1_launches = 0;       // step launches that counted on them so far
     uint32_t fc1_target_skew = 0;    // test aid (sc_selfplay_debug_break_handoff): arrivals that will never come
+    // An internal hand-off of a step launch timed out (error_flags & (16 | 32)): tiles were computed from stale rows, the
+    // values backed up since are wrong.  Latched when the host first sees the flag; from then on the handle refuses work.
+    bool poisoned = false;
 };
+
+static int sp_refuse(const sc_selfplay*) {
+    return fail("an internal hand-off of this handle's step launches timed out (error_flags & 48): its trees and traces are "
+                "invalid; destroy the handle -- a new handle on this device uses the two-launch step", SC_ERR_HANDOFF);
+}
+// called with the stream idle: looks at the device's error word
+static int sp_latch(sc_selfplay* sp) {
+    if (sp->poisoned) return 0;
+    int32_t err = 0;
+    HIPOK(hipMemcpy(&err, reinterpret_cast<const char*>(sp->p.cnt) + offsetof(sc::Counters, err), 4, hipMemcpyDeviceToHost));
+    if (err & (sc::ERR_HELPER_TIMEOUT | sc::ERR_HANDOFF_TIMEOUT)) {
+        sp->poisoned = true;
+        if (err & sc::ERR_HANDOFF_TIMEOUT) {
+            std::lock_guard<std::mutex> lk(g_fc1_mu);
+            g_fc1_failed[sp->device] = true;
+        }
+    }
+    return 0;
+}
 
 // complete the last enqueued simulation (expand / backward / ply transition) so that host reads see a
 // fully backed-up state; a following enqueue would have done the same work in its first launch
@@ -787,8 +839,9 @@ void sc_selfplay_destroy(sc_selfplay* sp) {
 int sc_selfplay_enable_timing(sc_selfplay* sp, int stride) {
     if (!sp) return fail("null handle");
     HIPOK(hipSetDevice(sp->device));
-    sp->timing_stride = stride;
-    if (stride > 0 && sp->ev.empty()) {
+    sp->timing_stride = stride > 0 ? stride : 0;
+    sp->step_stride = stride < 0 ? -stride : 0;
+    if (stride != 0 && sp->ev.empty()) {
         sp->ev.resize(2 * 4096);
         for (auto& ev : sp->ev) HIPOK(hipEventCreate(&ev));
         HIPOK(hipEventCreate(&sp->ev_begin));
@@ -799,10 +852,12 @@ int sc_selfplay_enable_timing(sc_selfplay* sp, int stride) {
 
 int sc_selfplay_enqueue_sims(sc_selfplay* sp, int n) {
     if (!sp || n < 0) return fail("bad argument");
+    if (sp->poisoned) return sp_refuse(sp);
     HIPOK(hipSetDevice(sp->device));
     hipStream_t s = sp->stream;
     const sc::SpParams& p = sp->p;
-    if (sp->timing_stride > 0 && !sp->have_span) {
+    const bool any_timing = sp->timing_stride > 0 || sp->step_stride > 0;
+    if (any_timing && !sp->have_span) {
         HIPOK(hipEventRecord(sp->ev_begin, s));
         sp->have_span = true;
     }
@@ -820,6 +875,19 @@ int sc_selfplay_enqueue_sims(sc_selfplay* sp, int n) {
             match_tail_params(sp, q, t - 1);
         }
         const bool timed = p.evaluator == SC_EVAL_NET && sp->timing_stride > 0 && (sp->nn_launches % sp->timing_stride) == 0;
+        // whole-step sampling (the dominant kernel of production is the step launch itself): the launch form is not changed
+        const bool step_timed = p.evaluator == SC_EVAL_NET && sp->step_stride > 0 && (sp->nn_launches % sp->step_stride) == 0;
+        int step_slot = 0;
+        if (step_timed) {
+            step_slot = sp->ev_next;
+            sp->ev_next = (sp->ev_next + 1) % 4096;
+            HIPOK(hipEventRecord(sp->ev[2 * step_slot], s));
+        }
+        auto step_timed_end = [&]() -> hipError_t {
+            if (!step_timed) return hipSuccess;
+            sp->ev_recorded++;
+            return hipEventRecord(sp->ev[2 * step_slot + 1], s);
+        };
         if (p.evaluator == SC_EVAL_NET && !timed && sp->fused) {
             // one launch: the game's search wave (finish the previous simulation, select + encode the next leaf) is wave 0
             // of its tower workgroup (step_kernels.hip); bit-identical to the two launches below
@@ -852,6 +920,7 @@ int sc_selfplay_enqueue_sims(sc_selfplay* sp, int n) {
                 f.vpart = sp->d_vpart;
                 scl::value_fc1(f, s);
             }
+            HIPOK(step_timed_end());
             sp->nn_launches++;
             continue;
         }
@@ -892,12 +961,13 @@ int sc_selfplay_enqueue_sims(sc_selfplay* sp, int n) {
             f.hval = sp->d_hval;
             f.vpart = sp->d_vpart;
             scl::value_fc1(f, s);   // the tail of the value head is fused into the next k_mcts launch
+            HIPOK(step_timed_end());
             sp->nn_launches++;
         }
     }
     if (n > 0) sp->pending_final = true;  // the last simulation is completed lazily (sp_flush) before any host read
     sp->sim_steps_enqueued += n;
-    if (sp->timing_stride > 0) HIPOK(hipEventRecord(sp->ev_end, s));
+    if (any_timing) HIPOK(hipEventRecord(sp->ev_end, s));
     HIPOK(hipGetLastError());
     return 0;
 }
@@ -938,7 +1008,9 @@ int sc_selfplay_synchronize(sc_selfplay* sp) {
     HIPOK(hipSetDevice(sp->device));
     sp_flush(sp);
     HIPOK(hipStreamSynchronize(sp->stream));
-    return 0;
+    int rc = sp_latch(sp);
+    if (rc) return rc;
+    return sp->poisoned ? sp_refuse(sp) : 0;
 }
 
 int sc_selfplay_get_stats(sc_selfplay* sp, sc_selfplay_stats* out) {
@@ -965,7 +1037,7 @@ int sc_selfplay_get_stats(sc_selfplay* sp, sc_selfplay_stats* out) {
     out->games_active = active;
     out->error_flags = c.err;
     out->plies_done = (int32_t)c.plies_done;
-    return 0;
+    return sp_latch(sp);   // (the statistics stay readable on a poisoned handle: that is how the host learns the flags)
 }
 
 int sc_selfplay_run(sc_selfplay* sp, int64_t max_sim_steps) {
@@ -983,6 +1055,7 @@ int sc_selfplay_run(sc_selfplay* sp, int64_t max_sim_steps) {
         sc_selfplay_stats st;
         rc = sc_selfplay_get_stats(sp, &st);
         if (rc) return rc;
+        if (sp->poisoned) return sp_refuse(sp);
         if (st.games_active == 0) break;
     }
     return 0;
@@ -1000,7 +1073,7 @@ int sc_selfplay_timing(sc_selfplay* sp, int reset, float* ms_total, float* ms_nn
     HIPOK(hipStreamSynchronize(sp->stream));
     float tot = 0.f, nn = 0.f;
     int64_t cnt = std::min<int64_t>(sp->ev_recorded, 4096);
-    if (sp->timing_stride > 0) {
+    if (sp->timing_stride > 0 || sp->step_stride > 0) {
         if (sp->have_span) HIPOK(hipEventElapsedTime(&tot, sp->ev_begin, sp->ev_end));
         for (int64_t k = 0; k < cnt; k++) {
             int slot = (int)(((int64_t)sp->ev_next - 1 - k + 4096 * 2) % 4096);
@@ -1033,9 +1106,13 @@ int sc_selfplay_get_trace(sc_selfplay* sp, int game, sc_trace_info* info, uint16
     // non-blocking).  Anything else is read from an idle stream.
     const bool held = sp->p.trace_hold && sp->reported[(size_t)game] == want_id + 1 &&
                       std::find(sp->to_release.begin(), sp->to_release.end(), game) != sp->to_release.end();
+    if (sp->poisoned) return sp_refuse(sp);
     if (!held) {
         sp_flush(sp);
         HIPOK(hipStreamSynchronize(sp->stream));
+        int lrc = sp_latch(sp);
+        if (lrc) return lrc;
+        if (sp->poisoned) return sp_refuse(sp);
     }
     const sc::SpParams& p = sp->p;
     sc::TraceHdr h;
@@ -1095,8 +1172,14 @@ int sc_selfplay_get_trace(sc_selfplay* sp, int game, sc_trace_info* info, uint16
 int sc_selfplay_poll(sc_selfplay* sp, int32_t* finished_games, int cap) {
     if (!sp || cap < 0 || (cap > 0 && !finished_games)) return fail("bad argument");
     HIPOK(hipSetDevice(sp->device));
+    if (sp->poisoned) return sp_refuse(sp);
     sp_flush(sp);
     HIPOK(hipStreamSynchronize(sp->stream));
+    {
+        int lrc = sp_latch(sp);
+        if (lrc) return lrc;
+        if (sp->poisoned) return sp_refuse(sp);   // nothing of this batch is reported: the games that "finished" are not real
+    }
     const sc::SpParams& p = sp->p;
     // rows handed out by the previous poll go back to the device (the stream is idle: no kernel reads them now)
     for (int row : sp->to_release) {
@@ -1128,6 +1211,11 @@ int sc_selfplay_debug_break_handoff(sc_selfplay* sp, int missing) {
     if (!sp->fc1_in_step) return 1;
     sp->fc1_target_skew += (uint32_t)missing;
     return 0;
+}
+
+int sc_debug_clear_handoff_failure(int device_id) {
+    std::lock_guard<std::mutex> lk(g_fc1_mu);
+    return g_fc1_failed.erase(device_id) ? 0 : 1;
 }
 
 int sc_debug_find_max(int device_id, const float* values, int n, int32_t* out2) {

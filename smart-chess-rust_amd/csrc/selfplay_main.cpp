@@ -19,6 +19,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <chrono>
 #include <string>
 #include <thread>
 #include <utility>
@@ -109,7 +110,7 @@ static int run_gpu(const Args& a, int gpu, int first, int count, int* finished_w
     }
     const int K = a.groups < 1 ? 1 : (a.groups > count ? count : a.groups);
     std::vector<sc_selfplay*> sps;
-    int rc = 0, off = 0;
+    int rc = 0, off = 0, total_slots = 0;
     for (int k = 0; k < K && !rc; k++) {
         const int cnt = count / K + (k < count % K ? 1 : 0);
         sc_selfplay_config c{};
@@ -141,19 +142,30 @@ static int run_gpu(const Args& a, int gpu, int first, int count, int* finished_w
             break;
         }
         sps.push_back(sp);
+        total_slots += c.n_slots;
         off += cnt;
     }
     // interleave the groups simulation step by simulation step; after every chunk (one ply's worth of steps) the games that
     // have ended are collected (sc_selfplay_poll: their trace rows stay untouched until the next poll), the NEXT chunk is
     // enqueued, and only then are their traces fetched and written -- the GPU searches while the host formats JSON
     int with_outcome = 0, finished = 0, errs = 0, written = 0;
-    long long sims = 0;
+    long long sims = 0, evals = 0, plies = 0;
+    // rates: over the whole run (engine creation excluded), and over the chunks during which every slot had a game (the ragged
+    // tail -- the last games finishing beside empty slots -- is what a finite job pays, not what the pipeline sustains)
+    using clk = std::chrono::steady_clock;
+    const auto t_start = clk::now();
+    auto t_prev = t_start;
+    long long sims_prev = 0, full_sims = 0;
+    double full_s = 0.0;
+
     const int chunk = a.rollout_num > 0 ? a.rollout_num : 300;
     std::vector<int32_t> fin(4096);
     std::vector<std::pair<size_t, int32_t>> todo;   // (group, game) reported by the polls of this round
+    bool was_full = false;
     rc = sc_selfplay_enqueue_interleaved(sps.data(), (int)sps.size(), chunk);
     while (!rc) {
         int active = 0;
+        long long sims_now = 0;
         bool more = false;   // a poll filled its buffer: poll again before anything else is enqueued
         todo.clear();
         for (size_t k = 0; k < sps.size() && !rc; k++) {
@@ -168,6 +180,18 @@ static int run_gpu(const Args& a, int gpu, int first, int count, int* finished_w
             sc_selfplay_stats st{};
             if (sc_selfplay_get_stats(sp, &st)) rc = 1;
             active += st.games_active;
+            sims_now += (long long)st.sims_done;
+            if (st.error_flags) rc = 1;   // invalid games must not reach training: stop, exit non-zero
+        }
+        {
+            const auto t_now = clk::now();
+            if (was_full && active >= total_slots) {
+                full_sims += sims_now - sims_prev;
+                full_s += std::chrono::duration<double>(t_now - t_prev).count();
+            }
+            was_full = active >= total_slots;
+            t_prev = t_now;
+            sims_prev = sims_now;
         }
         if (rc) break;
         if (active > 0 && !more) rc = sc_selfplay_enqueue_interleaved(sps.data(), (int)sps.size(), chunk);
@@ -191,13 +215,28 @@ static int run_gpu(const Args& a, int gpu, int first, int count, int* finished_w
         sc_selfplay_get_stats(sps[k], &st);
         finished += st.games_finished;
         sims += (long long)st.sims_done;
+        evals += (long long)st.nn_evals;
+        plies += (long long)st.plies_done;
         errs |= st.error_flags;
+    }
+    const double wall = std::chrono::duration<double>(clk::now() - t_start).count();
+    if (errs) {
+        fprintf(stderr, "gpu %d: error_flags %d -- the games of this run are not to be trusted (include/sc_engine.h: sc_selfplay_stats)\n", gpu, errs);
+        rc = 1;
     }
     if (!rc && written != count) {
         fprintf(stderr, "gpu %d: %d of %d traces written\n", gpu, written, count);
         rc = 1;
     }
     printf("gpu %d: games %d finished %d with-outcome %d simulations %lld error_flags %d\n", gpu, count, finished, with_outcome, sims, errs);
+    // one JSON object per GPU (sims/s, games/s, occupancy -> JSON)
+    printf("{\"gpu\": %d, \"games\": %d, \"finished\": %d, \"with_outcome\": %d, \"traces_written\": %d, \"simulations\": %lld, "
+           "\"nn_evals\": %lld, \"plies\": %lld, \"wall_s\": %.3f, \"sims_per_s\": %.1f, \"games_per_s\": %.3f, "
+           "\"full_occupancy_sims_per_s\": %.1f, \"full_occupancy_s\": %.3f, \"slots\": %d, \"groups\": %d, \"launches_per_step\": %d, "
+           "\"error_flags\": %d, \"ok\": %s}\n",
+           gpu, count, finished, with_outcome, written, sims, evals, plies, wall, wall > 0 ? sims / wall : 0.0, wall > 0 ? finished / wall : 0.0,
+           full_s > 0 ? full_sims / full_s : 0.0, full_s, total_slots, (int)sps.size(), sps.empty() ? 0 : sc_selfplay_launches_per_step(sps[0]),
+           errs, rc ? "false" : "true");
     *finished_with_outcome = with_outcome;
     for (sc_selfplay* sp : sps) sc_selfplay_destroy(sp);
     sc_engine_destroy(eng);

@@ -107,6 +107,10 @@ __global__ __launch_bounds__(256, 1) void k_step(scnn::TowerArgs A, sc::SpParams
 #ifdef SC_EXP
     if (p.dbg_cycles && threadIdx.x == 0) p.dbg_cycles[(size_t)g * 32 + 21] = t_entry;
 #endif
+    // phase stamps of the launch (sc_selfplay_debug_cycles; bench.py's per-phase split): 100 MHz wall clock at kernel entry
+    // [24], when the search wave has its leaf [25], at the end of the network [26] and of the value-FC tile [27]
+#define PHASE_STAMP(k, cond) do { if (p.dbg_cycles && (cond)) p.dbg_cycles[(size_t)g * 32 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+    PHASE_STAMP(24, threadIdx.x == 0);
     // wave 0: the game's search, wave 1: its helper (encodes the leaf's planes while wave 0 generates the moves); both run
     // inside the tower's prologue (tower_body, Pre), after every wave has requested its first weights
     if (threadIdx.x == 0) s_box.state = 0;   // LDS starts with whatever the previous workgroup left: clear the mailbox ...
@@ -124,11 +128,16 @@ __global__ __launch_bounds__(256, 1) void k_step(scnn::TowerArgs A, sc::SpParams
             __builtin_amdgcn_wave_barrier();
         }
         SC_STAMP(1);
-        return sc::dev_select<false>(p, g, lane, s_stage, s_moves, &s_pos, s_ps, s_hist, cs_pre, cs_pre_valid, &s_box);
+        const bool need_net = sc::dev_select<false>(p, g, lane, s_stage, s_moves, &s_pos, s_ps, s_hist, cs_pre, cs_pre_valid, &s_box);
+        PHASE_STAMP(25, lane == 0);
+        return need_net;
     };
     scnn::Fc1Hand fh;
     const bool ran = scnn::tower_body<P, C, RS, TPI, AB>(A, g, s_stage, search, fh);
+    PHASE_STAMP(26, threadIdx.x == 0);
     if (A.fc1_arrive) fc1_tail(A, p, g, ran, fh);
+    PHASE_STAMP(27, threadIdx.x == 0);
+#undef PHASE_STAMP
 }
 
 }  // namespace scstep

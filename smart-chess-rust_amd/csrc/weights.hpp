@@ -191,9 +191,19 @@ inline std::string load_scw(const char* path, HostWeights& w) {
             const size_t O = (size_t)tab[i].shape[0], per = numel / O;
             std::vector<uint8_t> q(numel);
             w.exps[i].resize(O);
-            if (!is_fp8_conv(w.n_blocks, (int)i) || fread(w.exps[i].data(), 1, O, f) != O || fread(q.data(), 1, numel, f) != numel) {
+            // (an e4m3 tensor belongs in a file whose header says fp8, and only the conv tensors are exported that way)
+            if (!w.fp8 || !is_fp8_conv(w.n_blocks, (int)i) || fread(w.exps[i].data(), 1, O, f) != O || fread(q.data(), 1, numel, f) != numel) {
                 fclose(f);
                 return "bad fp8 tensor at index " + std::to_string(i);
+            }
+            // channel exponents are clipped to +-100 by the exporter (tools/scw.py channel_exps, channel_exp() here); pack8()
+            // writes 127 + e as the E8M0 block scale, where 255 is the NaN code: a foreign or damaged blob must not load
+            bool ok = true;
+            for (size_t o = 0; o < O; o++) ok = ok && w.exps[i][o] >= -100 && w.exps[i][o] <= 100;
+            for (size_t k = 0; k < numel; k++) ok = ok && (q[k] & 0x7f) != 0x7f;   // the e4m3 NaN code is never exported
+            if (!ok) {
+                fclose(f);
+                return "bad fp8 tensor at index " + std::to_string(i) + " (channel exponent outside [-100, 100] or a NaN code)";
             }
             for (size_t k = 0; k < numel; k++) w.t[i][k] = ldexpf(e4m3_decode(q[k]), w.exps[i][k / per]);
         }

@@ -19,7 +19,10 @@ EVALUATORS = {"net": 0, "synth": 1, "synth_coarse": 2, "synth_uniform": 3}   # S
 
 
 class EngineError(RuntimeError):
-    pass
+    code = None
+
+
+ERR_HANDOFF = -5   # SC_ERR_HANDOFF: the self-play handle is poisoned (include/sc_engine.h)
 
 
 class NetConfig(C.Structure):
@@ -56,6 +59,7 @@ ABI = {
     "sc_selfplay_poll": (_i, [_vp, _vp, _i]),
     "sc_debug_find_max": (_i, [_i, _vp, _i, _vp]),
     "sc_selfplay_debug_break_handoff": (_i, [_vp, _i]),
+    "sc_debug_clear_handoff_failure": (_i, [_i]),
     "sc_selfplay_debug_cycles": (_i, [_vp, _i, _vp]),
     "sc_engine_create": (_i, [C.POINTER(NetConfig), C.c_char_p, _i, C.POINTER(_vp)]),
     "sc_engine_destroy": (None, [_vp]),
@@ -87,6 +91,7 @@ ABI = {
     "sc_selfplay_set_noise": (_i, [_vp, _i, _vp, _i]),
     "sc_selfplay_get_noise": (_i, [_vp, _i, _vp, _i]),
     "sc_selfplay_set_position": (_i, [_vp, _i, _vp, _i]),
+    "sc_encode_steps_last_timing": (_i, [C.POINTER(_f), C.POINTER(_f)]),
     "sc_encode_steps": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sc_trace_write_json": (_i, [C.c_char_p, C.POINTER(TraceInfo), _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sc_move_uci": (_i, [C.c_uint16, C.c_char_p]),
@@ -122,7 +127,9 @@ def lib():
 
 def _check(rc):
     if rc != 0:
-        raise EngineError(f"libsc_engine error {rc}: {lib().sc_last_error().decode()}")
+        e = EngineError(f"libsc_engine error {rc}: {lib().sc_last_error().decode()}")
+        e.code = rc
+        raise e
 
 
 def _p(a):
@@ -249,6 +256,13 @@ def encode_steps_batch(games, apply_mirror=False, device=0, engine=None):
                              int(bool(apply_mirror)), _p(boards), _p(meta), _p(dist), _p(li), _p(nl), _p(status)))
     return dict(boards=boards[:P], meta=meta[:P], dist=dist[:P], move_indices=[li[i, :nl[i]].astype(np.int32) for i in range(P)],
                 ply_off=off, status=status[:n])
+
+
+def encode_steps_last_timing():
+    """(kernel ms, whole-call ms) of this thread's last sc_encode_steps"""
+    a, b = C.c_float(0), C.c_float(0)
+    lib().sc_encode_steps_last_timing(C.byref(a), C.byref(b))
+    return a.value, b.value
 
 
 def encode_steps(steps, apply_mirror=False, device=0, engine=None):
@@ -575,6 +589,12 @@ class SelfPlay:
                                         _p(out["move"]), _p(out["first_child"]), _p(out["n_child"]))
         if r < 0:
             _check(r)
+        return out
+
+    def debug_cycles(self, enable=True, read=False):
+        """sc_selfplay_debug_cycles: switch the stamps on / read those of the last launch -> uint64[n_slots, 32] (or None)"""
+        out = np.zeros((self.cfg.n_slots, 32), np.uint64) if read else None
+        _check(self.L.sc_selfplay_debug_cycles(self.h, int(enable), _p(out)))
         return out
 
     def slot(self, slot):

@@ -33,6 +33,11 @@ def test_cli_writes_reference_traces(tmp_path, orc):
     r = _run("-d", "cuda", "--rollout-num", "24", "-n", "12", "--temperature", "0", "--cpuct", "2", "--temperature-switch", "4",
              "-t", pat, "--games", "6", "--concurrency", "4", "--blocks", "2", "--channels", "128", "--seed", "7")
     assert r.returncode == 0, r.stderr
+    # one JSON statistics object per GPU (sims/s, games/s, occupancy -> JSON)
+    stats = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(stats) == 1 and stats[0]["gpu"] == 0 and stats[0]["games"] == 6 and stats[0]["traces_written"] == 6
+    assert stats[0]["simulations"] == 6 * 12 * 24 and stats[0]["error_flags"] == 0 and stats[0]["ok"] is True
+    assert stats[0]["sims_per_s"] > 0 and stats[0]["launches_per_step"] in (1, 2, 3) and stats[0]["slots"] == 4
     for k in range(1, 7):
         js = json.load(open(str(tmp_path / f"trace{k}.json")))
         assert list(js.keys()) == ["outcome", "steps"] and len(js["steps"]) == 12 and js["outcome"] is None

@@ -169,3 +169,33 @@ def test_fp8_selfplay_edge_configurations(scamd, slots, games, R):
         assert t is not None and 1 <= len(t["steps"]) <= 3 and all(sum(c[1] for c in s[2]) == R - 1 for s in t["steps"])
     sp.close()
     eng.close()
+
+
+def test_corrupt_fp8_blobs_are_rejected_at_load(scamd, tmp_path):
+    """a channel exponent outside the exporter's [-100, 100] (127 + e is the E8M0 scale byte: -128 wraps to the
+    NaN code, 127 to 2^127), an e4m3 NaN code, or an e4m3 tensor in a blob whose header says bf16 must fail the load --
+    not produce an engine whose activations are NaN or inf"""
+    import struct
+    import scw
+    sd = scw.prng_state_dict(1, 128, 3)
+    good = str(tmp_path / "good8.scw")
+    scw.write_scw(good, sd, 1, 128, fp8=True)
+    blob = bytearray(open(good, "rb").read())
+    # first tensor of the table is the stem conv (e4m3): header 20 B, tensor header 28 B + enc 4 B, then its exponents
+    assert struct.unpack("<I", blob[20 + 28:20 + 32])[0] == 1
+    e0 = 20 + 32
+    n_out = struct.unpack("<I", blob[20 + 4:20 + 8])[0]
+    scamd.Engine(weights=good).close()
+    for name, patch in (("exp_minus128", (e0, 0x80)), ("exp_plus127", (e0 + 5, 0x7F)), ("exp_101", (e0 + 1, 101)),
+                        ("nan_code", (e0 + n_out + 17, 0x7F)), ("neg_nan_code", (e0 + n_out + 18, 0xFF)), ("header_says_bf16", (16, 0))):
+        bad = bytearray(blob)
+        bad[patch[0]] = patch[1]
+        p = str(tmp_path / f"{name}.scw")
+        open(p, "wb").write(bytes(bad))
+        with pytest.raises(scamd.EngineError, match="bad fp8 tensor"):
+            scamd.Engine(weights=p)
+    ok = bytearray(blob)
+    ok[e0] = 0x9C   # -100: the edge of the range still loads
+    p = str(tmp_path / "edge.scw")
+    open(p, "wb").write(bytes(ok))
+    scamd.Engine(weights=p).close()
