@@ -303,6 +303,11 @@ static int forward_host(sc_engine* e, int n, const int8_t* boards, const int32_t
         HIPOK(hipMemcpyAsync(e->d_lidx, lidx_rows, (size_t)n * 224 * 2, hipMemcpyHostToDevice, s));
         HIPOK(hipMemcpyAsync(e->d_nlegal, nlegal, (size_t)n * 4, hipMemcpyHostToDevice, s));
     }
+#ifdef SC_EXP   // experiment builds: the same launches back to back first (steady clocks for in-kernel stamps, tools/dbg_clock.py)
+    for (int rep = getenv("SC_EXP_REPEAT") ? atoi(getenv("SC_EXP_REPEAT")) : 0; rep > 0; rep--)
+        enqueue_forward(e, n, e->d_boards, e->d_meta, 8, lidx_rows ? e->d_lidx : nullptr, lidx_rows ? e->d_nlegal : nullptr,
+                        e->d_prior, e->d_value, logp ? e->d_logp : nullptr, dbg ? e->d_dbg : nullptr, dbg_stage, s);
+#endif
     enqueue_forward(e, n, e->d_boards, e->d_meta, 8, lidx_rows ? e->d_lidx : nullptr, lidx_rows ? e->d_nlegal : nullptr,
                     e->d_prior, e->d_value, logp ? e->d_logp : nullptr, dbg ? e->d_dbg : nullptr, dbg_stage, s);
     HIPOK(hipGetLastError());
@@ -457,19 +462,20 @@ int sc_encode_steps(sc_engine* e, int device_id, int n_games, const uint16_t* mo
     for (uint32_t p = 0; p < total; p++)
         if (child_off[p + 1] < child_off[p] || child_off[p + 1] - child_off[p] > 224) return fail("child_off: more than 224 children or not monotonic");
     if (total == 0) return 0;
-    // one position per ply: (start of its game, number of moves already played)
+    // one position per ply: (record index of its game's start position, number of moves already played)
+    const int hist_cap = (int)maxlen + 2;
     std::vector<uint32_t> pstart(total), plen(total), pgame(total);
     for (int g = 0; g < n_games; g++)
         for (uint32_t t = move_off[g]; t < move_off[g + 1]; t++) {
-            pstart[t] = move_off[g];
+            pstart[t] = (uint32_t)g * (uint32_t)hist_cap;
             plen[t] = t - move_off[g];
             pgame[t] = (uint32_t)g;
         }
-    const int hist_cap = (int)maxlen + 2;
-    const uint32_t CH = 8192;  // plies per launch (bounds the replay scratch: CH * hist_cap * 80 B)
+    if ((size_t)n_games * (size_t)hist_cap > (size_t)0xffffffffu) return fail("too many game records for one call");
+    const uint32_t CH = 8192;  // plies per launch of the per-ply kernels (bounds the output staging: CH * 26 KB)
     const uint32_t nchild = child_off[total];
     uint16_t *d_moves = nullptr, *d_cmv = nullptr, *d_lm = nullptr, *d_li = nullptr;
-    uint32_t *d_start = nullptr, *d_len = nullptr, *d_cn = nullptr, *d_coff = nullptr;
+    uint32_t *d_start = nullptr, *d_len = nullptr, *d_cn = nullptr, *d_coff = nullptr, *d_moff = nullptr;
     sc::Position* d_hist = nullptr;
     int8_t* d_boards = nullptr;
     int32_t *d_meta = nullptr, *d_nl = nullptr, *d_flags = nullptr, *d_out = nullptr;
@@ -481,7 +487,8 @@ int sc_encode_steps(sc_engine* e, int device_id, int n_games, const uint16_t* mo
     HIPOK(dalloc(&d_coff, (size_t)cap + 1));
     HIPOK(dalloc(&d_start, cap));
     HIPOK(dalloc(&d_len, cap));
-    HIPOK(dalloc(&d_hist, (size_t)cap * hist_cap));
+    HIPOK(dalloc(&d_hist, (size_t)n_games * hist_cap));   // one 80-byte record per ply of every game (k_replay_games)
+    HIPOK(dalloc(&d_moff, (size_t)n_games + 1));
     HIPOK(dalloc(&d_boards, (size_t)cap * 7168));
     HIPOK(dalloc(&d_meta, (size_t)cap * 7));
     HIPOK(dalloc(&d_nl, cap));
@@ -491,6 +498,7 @@ int sc_encode_steps(sc_engine* e, int device_id, int n_games, const uint16_t* mo
     HIPOK(dalloc(&d_li, (size_t)cap * 224));
     HIPOK(dalloc(&d_dist, (size_t)cap * 4672));
     HIPOK(hipMemcpy(d_moves, moves, (size_t)total * 2, hipMemcpyHostToDevice));
+    HIPOK(hipMemcpy(d_moff, move_off, ((size_t)n_games + 1) * 4, hipMemcpyHostToDevice));
     if (nchild) {
         HIPOK(hipMemcpy(d_cmv, child_mv, (size_t)nchild * 2, hipMemcpyHostToDevice));
         HIPOK(hipMemcpy(d_cn, child_n, (size_t)nchild * 4, hipMemcpyHostToDevice));
@@ -501,15 +509,21 @@ int sc_encode_steps(sc_engine* e, int device_id, int n_games, const uint16_t* mo
     HIPOK(hipEventCreate(&evk[0]));
     HIPOK(hipEventCreate(&evk[1]));
     float kernels_ms = 0.f;
+    // every game is walked once (make_move, key, repetition flags: one record per ply); the plies are encoded from the records
+    HIPOK(hipEventRecord(evk[0], nullptr));
+    scl::replay_games(n_games, d_moves, d_moff, d_hist, hist_cap, nullptr);
+    HIPOK(hipEventRecord(evk[1], nullptr));
+    HIPOK(hipGetLastError());
+    HIPOK(hipDeviceSynchronize());
+    HIPOK(hipEventElapsedTime(&kernels_ms, evk[0], evk[1]));
     for (uint32_t p0 = 0; p0 < total; p0 += CH) {
         const uint32_t n = std::min(CH, total - p0);
         for (uint32_t i = 0; i <= n; i++) coff[i] = child_off[p0 + i];   // absolute offsets into d_cmv / d_cn
         HIPOK(hipMemcpy(d_coff, coff.data(), ((size_t)n + 1) * 4, hipMemcpyHostToDevice));
         HIPOK(hipMemcpy(d_start, pstart.data() + p0, (size_t)n * 4, hipMemcpyHostToDevice));
         HIPOK(hipMemcpy(d_len, plen.data() + p0, (size_t)n * 4, hipMemcpyHostToDevice));
-        HIPOK(hipMemset(d_li, 0, (size_t)n * 224 * 2));
         HIPOK(hipEventRecord(evk[0], nullptr));
-        scl::encode_positions((int)n, d_moves, d_start, d_len, d_hist, hist_cap, d_boards, d_meta, d_lm, d_li, d_nl, d_out, nullptr);
+        scl::encode_plies((int)n, d_hist, d_start, d_len, d_boards, d_meta, d_lm, d_li, d_nl, nullptr);
         // the ply's own move is moves[start + len] = d_moves + p0 + i
         scl::steps_dist((int)n, d_lm, d_nl, d_moves + p0, d_cmv, d_cn, d_coff, apply_mirror, d_meta, d_dist, d_flags, nullptr);
         HIPOK(hipEventRecord(evk[1], nullptr));
@@ -535,7 +549,7 @@ int sc_encode_steps(sc_engine* e, int device_id, int n_games, const uint16_t* mo
             else if (flags[i] & 2) status[g] = -(ply + 1);
         }
     }
-    dfree({d_moves, d_cmv, d_cn, d_coff, d_start, d_len, d_hist});
+    dfree({d_moves, d_cmv, d_cn, d_coff, d_start, d_len, d_hist, d_moff});
     dfree({d_boards, d_meta, d_nl, d_flags, d_out, d_lm, d_li, d_dist});
     (void)hipEventDestroy(evk[0]);
     (void)hipEventDestroy(evk[1]);

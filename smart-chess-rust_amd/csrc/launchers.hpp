@@ -15,6 +15,9 @@ void set_position(const sc::SpParams& p, int slot, const uint16_t* d_moves, int 
 void encode_positions(int n_pos, const uint16_t* d_moves, const uint32_t* d_move_off, const uint32_t* d_move_len, sc::Position* d_hist,
                       int hist_cap, int8_t* boards, int32_t* meta, uint16_t* legal_mv, uint16_t* legal_idx, int32_t* n_legal,
                       int32_t* outcome, hipStream_t s);
+void replay_games(int n_games, const uint16_t* d_moves, const uint32_t* d_move_off, sc::Position* d_hist, int hist_cap, hipStream_t s);
+void encode_plies(int n, const sc::Position* d_hist, const uint32_t* d_hoff, const uint32_t* d_plen, int8_t* boards, int32_t* meta,
+                  uint16_t* legal_mv, uint16_t* legal_idx, int32_t* n_legal, hipStream_t s);
 void steps_dist(int n, const uint16_t* legal_mv, const int32_t* n_legal, const uint16_t* next_mv, const uint16_t* child_mv,
                 const uint32_t* child_n, const uint32_t* child_off, int apply_mirror, int32_t* meta, float* dist, int32_t* flags,
                 hipStream_t s);

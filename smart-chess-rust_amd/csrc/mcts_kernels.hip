@@ -20,6 +20,15 @@ void encode_positions(int n_pos, const uint16_t* d_moves, const uint32_t* d_move
     hipLaunchKernelGGL(sc::k_encode_positions, dim3(n_pos), dim3(64), 0, s, n_pos, d_moves, d_move_off, d_move_len, d_hist, hist_cap,
                        boards, meta, legal_mv, legal_idx, n_legal, outcome);
 }
+void replay_games(int n_games, const uint16_t* d_moves, const uint32_t* d_move_off, sc::Position* d_hist, int hist_cap, hipStream_t s) {
+    if (n_games <= 0) return;
+    hipLaunchKernelGGL(sc::k_replay_games, dim3(n_games), dim3(64), 0, s, n_games, d_moves, d_move_off, d_hist, hist_cap);
+}
+void encode_plies(int n, const sc::Position* d_hist, const uint32_t* d_hoff, const uint32_t* d_plen, int8_t* boards, int32_t* meta,
+                  uint16_t* legal_mv, uint16_t* legal_idx, int32_t* n_legal, hipStream_t s) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(sc::k_encode_plies, dim3(n), dim3(64), 0, s, n, d_hist, d_hoff, d_plen, boards, meta, legal_mv, legal_idx, n_legal);
+}
 void steps_dist(int n, const uint16_t* legal_mv, const int32_t* n_legal, const uint16_t* next_mv, const uint16_t* child_mv,
                 const uint32_t* child_n, const uint32_t* child_off, int apply_mirror, int32_t* meta, float* dist, int32_t* flags,
                 hipStream_t s) {

@@ -1277,6 +1277,76 @@ __global__ __launch_bounds__(64) void k_encode_positions(int n_pos, const uint16
 }
 #endif
 
+// ------------------------------------------------------------------ trace replay for the training-tensor encoder
+// sc_encode_steps needs every ply of every game.  Replaying each ply's prefix in its own wave (k_encode_positions) is
+// O(plies^2) make_move + move generations per game; here a game is walked ONCE by one wave -- make_move, transposition key,
+// repetition flags, one 80-byte record per ply -- and the plies are then encoded in parallel from those records
+// (k_encode_plies).  The walk does not validate the moves (that needs a move generation per ply: the per-ply kernel has
+// one anyway, and k_steps_dist checks the played move against it); it only refuses moves make_move could not execute
+// safely -- no piece of the mover on the from-square, an own piece on the target, a promotion code outside {0, N, B, R, Q}
+// or on a non-pawn -- and leaves the position unchanged for those (the ply is then reported as illegal by the per-ply check,
+// and the game's later plies are unspecified, include/sc_engine.h).
+#ifndef SC_NO_KERNELS
+__global__ __launch_bounds__(64) void k_replay_games(int n_games, const uint16_t* moves, const uint32_t* move_off, Position* hist_all,
+                                                     int hist_cap) {
+    const int g = blockIdx.x, lane = threadIdx.x;
+    if (g >= n_games) return;
+    __shared__ Position s_np;
+    Position* hist = hist_all + (size_t)g * hist_cap;
+    const uint16_t* mv = moves + move_off[g];
+    const int nm = (int)(move_off[g + 1] - move_off[g]);
+    Position cur;
+    set_startpos(cur);
+    cur.key = position_key(cur);
+    if (lane == 0) hist[0] = cur;
+    __syncthreads();
+    for (int i = 0; i < nm && i + 1 < hist_cap; i++) {
+        const move_t m = mv[i];
+        const int from = mv_from(m), to = mv_to(m), promo = mv_promo(m);
+        const bool ours = (occ_c(cur, cur.turn) & bit(from)) != 0, own_target = (occ_c(cur, cur.turn) & bit(to)) != 0;
+        const bool promo_ok = promo == 0 || (promo >= 2 && promo <= 5 && (cur.pcs[PAWN] & bit(from)) != 0);
+        if (ours && !own_target && promo_ok && from != to) make_move(cur, m);
+        if (lane == 0) s_np = cur;
+        __syncthreads();
+        DevChain ch{hist, i, hist, nullptr, &s_np, i + 1};
+        uint8_t rf = rep_flags_wave(ch, i + 1, cur.key, lane);
+        cur.flags = (uint8_t)((cur.flags & F_IRREV) | rf);
+        __syncthreads();
+        if (lane == 0) hist[i + 1] = cur;
+        __threadfence_block();
+        __syncthreads();
+    }
+}
+
+// one wave per ply: the position BEFORE the ply's move from the game's records -- legal moves (python-chess order), action
+// indices, planes, meta.  hoff[p]: record index of the game's start position, plen[p]: moves played before the ply.
+__global__ __launch_bounds__(64) void k_encode_plies(int n, const Position* hist_all, const uint32_t* hoff, const uint32_t* plen, int8_t* boards,
+                                                     int32_t* meta, uint16_t* legal_mv, uint16_t* legal_idx, int32_t* n_legal) {
+    const int g = blockIdx.x, lane = threadIdx.x;
+    if (g >= n) return;
+    __shared__ __attribute__((aligned(16))) int8_t s_stage[7168];
+    __shared__ move_t s_moves[MAXC];
+    __shared__ int32_t s_meta[8];
+    __shared__ Position s_hist[8];
+    const HistChain hc{hist_all + hoff[g]};
+    const int played = (int)plen[g];
+    stage_history(hc, played, lane, s_hist);
+    __syncthreads();
+    const Position cur = s_hist[0];
+    int nl = 0;
+    gen_legal_wave(cur, s_moves, lane, nl);
+    __syncthreads();
+    for (int i = lane; i < MAXC; i += 64) {   // whole rows: the entries past n_legal are zero (include/sc_engine.h)
+        legal_mv[(size_t)g * MAXC + i] = i < nl ? s_moves[i] : (move_t)0;
+        legal_idx[(size_t)g * MAXC + i] = i < nl ? (uint16_t)move_index(s_moves[i], cur.turn) : (uint16_t)0;
+    }
+    if (lane == 0) n_legal[g] = nl;
+    encode_wave(s_hist, played < 7 ? played + 1 : 8, lane, s_stage, boards + (size_t)g * 7168, s_meta);
+    __syncthreads();
+    if (lane < 7) meta[(size_t)g * 7 + lane] = s_meta[lane];
+}
+#endif
+
 // ------------------------------------------------------------------ training tensors
 // Per ply of a recorded game: libsmartchess.chess_encode_steps (reference src/lib.rs:46-128) on top of
 // k_encode_positions (planes / meta / legal moves of the position BEFORE the ply's move):

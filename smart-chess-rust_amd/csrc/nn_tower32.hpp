@@ -526,6 +526,10 @@ __device__ __forceinline__ bool tower_body(const TowerArgs& A, const int pos, co
     const int i32 = lane & 31, h = lane >> 5;
     const NetDev& net = A.net;
 #ifdef SC_EXP
+    // stage 2001 (tools/dbg_clock.py): shader-clock and wall-clock stamps around the whole tower of this workgroup
+    const bool clk_on = A.dbg && A.dbg_stage == 2001 && tid == 0;
+    const long long clk_t0 = clk_on ? clock64() : 0;
+    const unsigned long long clk_r0 = clk_on ? __builtin_amdgcn_s_memrealtime() : 0;
     Stamp stampv;
     stampv.on = A.dbg && A.dbg_stage == 2000 && lane == 0;
     stampv.prev = 0;
@@ -783,7 +787,8 @@ __device__ __forceinline__ bool tower_body(const TowerArgs& A, const int pos, co
                 const int c0 = chan0<NTW>(wave, lane);
 #pragma unroll
                 for (int k = 0; k < NTW; k++)
-                    s_scl[c0 + k] = __frcp_rn(1.0f + __expf(-(sc[k][0] + sb2[k])));
+                    // v_exp_f32 + v_rcp_f32 (1 ulp each): the correctly rounded reciprocal expands to a 20-instruction division
+                    s_scl[c0 + k] = __builtin_amdgcn_rcpf(1.0f + __expf(-(sc[k][0] + sb2[k])));
             }
         }
         SC_MARK(11);
@@ -1012,6 +1017,11 @@ __device__ __forceinline__ bool tower_body(const TowerArgs& A, const int pos, co
     SC_MARK(15);
     if (stampv.on)
         for (int k = 0; k < 40; k++) A.dbg[(size_t)pos * 64 * C + wave * 40 + k] = (float)stampv.t[k];
+    if (clk_on) {
+        A.dbg[(size_t)pos * 64 * C + 0] = (float)(clock64() - clk_t0);                               // s_memtime ticks
+        A.dbg[(size_t)pos * 64 * C + 1] = (float)(__builtin_amdgcn_s_memrealtime() - clk_r0);       // 100 MHz ticks
+        A.dbg[(size_t)pos * 64 * C + 2] = (float)(clk_r0 & 0xffffff);                               // start time (low bits): who ran when
+    }
 #endif
     return true;
 }
