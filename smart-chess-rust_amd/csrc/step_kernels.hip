@@ -91,7 +91,12 @@ __device__ __forceinline__ void fc1_tail(const scnn::TowerArgs& A, const sc::SpP
 
 template <class P, int C, int RS, int TPI, int AB>
 __global__ __launch_bounds__(256, 1) void k_step(scnn::TowerArgs A, sc::SpParams p, int do_expand) {
-    __shared__ __attribute__((aligned(16))) int8_t s_stage[7168];
+    // The leaf's 7 KB of input planes are handed from the search to the tower inside the tower's own dynamic LDS: the area of the
+    // policy head's image (behind the haloed image, nn_tower32.hpp: Xh), which nothing touches before the policy head.  As a static
+    // array of its own it made the bf16 workgroup 83.5 KB -- 1.6 KB too many for two of them on a CU (160 KB).
+    constexpr int XA = (100 * scnn::pix_stride<P>(C) > 4864 * 4) ? 100 * scnn::pix_stride<P>(C) : 4864 * 4;
+    static_assert(64 * scnn::pix_stride<P>(scnn::HEAD) >= 7168 && XA % 16 == 0, "the planes must fit the policy head's image area");
+    int8_t* const s_stage = reinterpret_cast<int8_t*>(scnn::g_smem) + XA;
     __shared__ sc::move_t s_moves[sc::MAXC];
     __shared__ sc::Position s_pos;
     __shared__ sc::Position s_hist[8];
