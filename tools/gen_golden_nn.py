@@ -122,6 +122,27 @@ def main():
                             n_params=np.int64(sum(p.numel() for p in model.parameters())))
         print(n_blocks, "blocks:", logp.shape, value.reshape(-1)[:4], "params", sum(p.numel() for p in model.parameters()))
 
+    # A trained network's outputs are not those of a U(-k, k) init: its log-probabilities reach magnitudes of 12-21
+    # (reference notebooks/check_model.ipynb cells 6-8) and its value leaves the linear part of tanh.  Same PRNG weights with
+    # the gain of the policy head's last LayerNorm x 4 and value_head.ffn.2.weight x 2: logits of that magnitude, through the
+    # reference module, as a second set of vectors.
+    path = os.path.join(out_dir, "nn_ref_b10_c256_sharp.npz")
+    if not os.path.exists(path) or "--force" in sys.argv:
+        n_blocks, seed = 10, 20260601
+        model = refmod.load_model(n_res_blocks=n_blocks, device="cpu", compile=False, inference=True)
+        new = scw.prng_state_dict(n_blocks, 256, seed=seed)
+        new["policy_head.model.3.weight"] = new["policy_head.model.3.weight"] * np.float32(4.0)
+        new["value_head.ffn.2.weight"] = new["value_head.ffn.2.weight"] * np.float32(2.0)
+        model.load_state_dict({k: torch.from_numpy(v) for k, v in new.items()}, strict=True)
+        inp = torch.from_numpy(boards.astype(np.float32)).permute(0, 3, 1, 2).contiguous()
+        meta = torch.from_numpy(metas.astype(np.float32))
+        with torch.no_grad():
+            logp, value = model(inp, meta)
+        np.savez_compressed(path, names=np.array(names), boards=boards, meta=metas, logp=logp.numpy().astype(np.float32),
+                            value=value.numpy().astype(np.float32).reshape(-1), seed=np.int64(seed), policy_gain_scale=np.float32(4.0),
+                            value_fc2_scale=np.float32(2.0))
+        print("sharp 10 blocks: logp range", float(logp.min()), float(logp.max()), "values", value.reshape(-1))
+
 
 if __name__ == "__main__":
     main()
