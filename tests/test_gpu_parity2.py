@@ -18,6 +18,15 @@ RTOL = ATOL = 1e-2   # reference convention, scripts/eval_speed.py:40-43
 # 18 plies from the start position to a White-to-move position with 82 legal moves (found by a beam search on the
 # oracle's move generator, tools/find_wide_position.py): the root of a search from here has more than 64 children
 WIDE = ("e2e3 d7d5 d1g4 d8d6 f1b5 e8d8 b1c3 d6h2 c3d5 h2d6 h1h6 d6a3 b2b3 a3a4 c1b2 c7c5 b2e5 a4b3").split()
+# 112 plies to a White-to-move position with 137 legal moves (seven white queens; found by a promotion-driven greedy search on
+# the oracle's move generator): a root with more than 128 children -- the third round of lanes of the descent's wide level
+WIDE137 = ("h2h4 g8h6 a2a4 h6g4 f2f4 g4h6 a4a5 h6g4 d2d4 g4f2 e1f2 b8a6 h4h5 a6b4 c2c4 b4c2 "
+           "d1c2 d7d5 c4c5 e8d7 f4f5 d7e8 c2a4 b7b5 a5b6 c7c6 a4c6 c8d7 c6d5 f7f6 b6b7 d8c8 "
+           "c5c6 e8d8 d5a5 d8e8 c6d7 e8f7 a5a2 c8c4 a2c4 e7e6 b7a8q f7g8 d7d8q g8f7 f5e6 f7g8 "
+           "g2g4 a7a5 d4d5 g7g6 h5h6 f6f5 g4g5 a5a4 e6e7 g8f7 e7e8q f7g8 b2b4 f5f4 e2e4 f4f3 "
+           "e4e5 a4a3 e5e6 a3a2 e6e7 a2b1q a1a6 b1f5 d5d6 f5f7 d6d7 f7d5 a6g6 h7g6 e7f8q g8h7 "
+           "d8e7 d5f7 d7d8q h8g8 e8f7 h7h8 h6h7 g8f8 b4b5 f8g8 b5b6 g8e8 b6b7 e8g8 b7b8q g8e8 "
+           "h1h2 e8g8 c4c2 g8e8 e7e4 e8g8 a8a3 g8e8 f7e8 h8g7 f2g3 f3f2 e8e5 g7f7 h7h8q f2g1b").split()
 MATED = ["f2f3", "e7e5", "g2g4", "d8h4"]   # White is checkmated: a game set to this line ends after its first search
 
 
@@ -124,6 +133,36 @@ def test_search_wide_root_lockstep_exact(scamd, orc):
     # the chosen children of the wide root come from both rounds (index < 64 and >= 64)
     kids = sp.tree(1)["n"][1:83]
     assert kids[:64].sum() > 0 and kids[64:].sum() > 0
+    assert sp.stats()["error_flags"] == 0
+
+
+@pytest.mark.parametrize("evaluator,oeval", [("synth", "orc_eval_synth"), ("synth_uniform", "orc_eval_synth_uniform"), ("synth_coarse", "orc_eval_synth_coarse")])
+def test_search_root_with_more_than_128_children_lockstep_exact(scamd, orc, evaluator, oeval):
+    """no search test reached a node with more than 128 children (rounds 3-4 of the wide arg-max ran only
+    in the crafted-value test).  Root with 137 legal moves after a 112-ply line (full 8-board history, halfmove clock and
+    repetition bookkeeping of a long game): node pools, uct words and paths equal the oracle after every simulation, with the
+    hash evaluator and with both tie evaluators (uniform: children are visited last to first, so the first descents take
+    children 136, 135, ... from the third round of lanes)."""
+    R = 220
+    sp = scamd.SelfPlay(None, n_slots=2, n_games=2, rollout_num=R, num_steps=130, cpuct=2.5, with_noise=False, evaluator=evaluator, seed=3)
+    st = _pushed(orc, WIDE137)
+    assert len(st.legal_moves()) == 137 and st.turn == 1
+    sp.set_position(1, WIDE137)
+    srch = orc.Search(st)
+    for s in range(R - 1):
+        sp.enqueue(1)
+        srch.sim(evaluator=oeval, cpuct=2.5, with_noise=False)
+        path = list(sp.slot(1)["path"])
+        assert path == list(srch.last_path()), s
+        if evaluator == "synth_uniform" and s == 1:
+            assert path[1] == 137, s                  # the LAST maximal child (src/mcts.rs:78-88): node 137 = child 136, from lanes' round 3
+                                                      # (later descents follow the oracle: mating moves among the 137 break the pure tie pattern)
+        if s % 7 == 0 or s > R - 4:
+            assert _same_tree(sp.tree(1), srch.dump()), s
+    t = sp.tree(1)
+    assert t["n_child"][0] == 137 and np.count_nonzero(t["uct"][1:138]) == 137     # every child's uct word was computed (and compared)
+    if evaluator == "synth_uniform":
+        assert (t["n"][1 + 128:1 + 137] > 0).all()    # every child of the third round of lanes was chosen (child 128 mates: it then takes the rest)
     assert sp.stats()["error_flags"] == 0
 
 
