@@ -64,10 +64,15 @@ __device__ __forceinline__ void fc1_tail(const scnn::TowerArgs& A, const sc::SpP
         uint32_t seen = ran ? fh.early : __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         while ((int32_t)(seen - A.fc1_target) < 0) {
             __builtin_amdgcn_s_sleep(4);
-            if (__builtin_amdgcn_s_memrealtime() - t0 > 20000000ull) {
+            const uint64_t waited = __builtin_amdgcn_s_memrealtime() - t0;
+            if (waited > 20000000ull) {
                 atomicOr(&p.cnt->err, sc::ERR_HANDOFF_TIMEOUT);
                 break;
             }
+            // A hand-off of this handle has already timed out (this launch or an earlier one): its results are invalid anyway and
+            // the host refuses the handle as soon as it looks (SC_ERR_HANDOFF).  Every later launch waiting its own 0.2 s would
+            // turn a queue of thousands of launches into a stall of many minutes: after 1 ms of waiting, give up as well.
+            if (waited > 100000ull && (__hip_atomic_load(&p.cnt->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & sc::ERR_HANDOFF_TIMEOUT)) break;
             seen = __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         TSTAMP(1);
