@@ -871,6 +871,17 @@ __device__ __forceinline__ void dev_expand(SpParams& p, int g, int lane, Positio
     // AFTER the last of them -- a readfirstlane right behind its load (or a load under `cond ? load : 0`, which becomes
     // a branch around the load with its own wait) parks the wave for a full round trip before the next load is even
     // issued: the kernel used to start with three serialised trips (control block, path, the rest).
+    // ... and the kernel arguments those addresses are made of are fetched TOGETHER: left to itself the compiler reads each of
+    // them (scattered over the argument block's cache lines) where it is first used, behind a wait of its own -- 3 k cycles
+    // passed between the entry of this function and the issue of its last load (tools/dbg_expand.py).  The empty asm statement
+    // wants them all in SGPRs at one point: one batch of scalar loads, one wait.
+    {
+        const void *a0 = p.ctl, *a1 = p.path, *a2 = p.prior, *a3 = p.legal_mv, *a4 = p.slot_cnt, *a5 = p.vpart, *a6 = p.vf_w, *a7 = p.meta;
+        const int i0 = p.max_depth, i1 = p.vf_fused, i2 = p.n_slots, i3 = p.vf_ksplit;
+        const uint32_t u0 = p.vf_fc1b, u1 = p.vf_fc1m, u2 = p.vf_fc2w, u3 = p.vf_fc2b;
+        asm volatile("" ::"s"(a0), "s"(a1), "s"(a2), "s"(a3), "s"(a4), "s"(a5), "s"(a6), "s"(a7), "s"(i0), "s"(i1), "s"(i2), "s"(i3), "s"(u0), "s"(u1),
+                     "s"(u2), "s"(u3));
+    }
     const GameCtl craw = c;
     const int pth_raw = p.path[(size_t)g * p.max_depth + (lane < p.max_depth ? lane : p.max_depth - 1)];
     float prv[4];
