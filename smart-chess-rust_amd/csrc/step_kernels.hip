@@ -94,14 +94,15 @@ __device__ __forceinline__ void fc1_tail(const scnn::TowerArgs& A, const sc::SpP
 #endif
 }
 
-template <class P, int C, int RS, int TPI, int AB>
+// STAMPS: the instantiation with the launch's phase stamps (bench.py's per-phase split; the headline's kernel only).  Compiled into
+// every launch they cost 0.5 % (same-box A/B), so the engine launches this variant only while stamps are switched on.
+template <class P, int C, int RS, int TPI, int AB, bool STAMPS = false>
 __global__ __launch_bounds__(256, 1) void k_step(scnn::TowerArgs A, sc::SpParams p, int do_expand) {
-    // The leaf's 7 KB of input planes are handed from the search to the tower inside the tower's own dynamic LDS: the area of the
-    // policy head's image (behind the haloed image, nn_tower32.hpp: Xh), which nothing touches before the policy head.  As a static
-    // array of its own it made the bf16 workgroup 83.5 KB -- 1.6 KB too many for two of them on a CU (160 KB).
-    constexpr int XA = (100 * scnn::pix_stride<P>(C) > 4864 * 4) ? 100 * scnn::pix_stride<P>(C) : 4864 * 4;
-    static_assert(64 * scnn::pix_stride<P>(scnn::HEAD) >= 7168 && XA % 16 == 0, "the planes must fit the policy head's image area");
-    int8_t* const s_stage = reinterpret_cast<int8_t*>(scnn::g_smem) + XA;
+    // (Round 3 tried the 7 KB plane staging inside the tower's dynamic LDS -- the policy head's image area, free until the heads -- to
+    // get the bf16 workgroup from 83.5 to 76 KB, two per CU: 512 bf16 games then run the one-launch step, 2.47 M simulations/s against
+    // 2.28 M in three launches.  But the 256-game headline lost 2.3 % (same-box A/B against this form; the compiler can no longer tell
+    // the staging area from the tower's other LDS traffic), and two interleaved groups serve 512 games better anyway: reverted.)
+    __shared__ __attribute__((aligned(16))) int8_t s_stage[7168];
     __shared__ sc::move_t s_moves[sc::MAXC];
     __shared__ sc::Position s_pos;
     __shared__ sc::Position s_hist[8];
@@ -119,7 +120,7 @@ __global__ __launch_bounds__(256, 1) void k_step(scnn::TowerArgs A, sc::SpParams
 #endif
     // phase stamps of the launch (sc_selfplay_debug_cycles; bench.py's per-phase split): 100 MHz wall clock at kernel entry
     // [24], when the search wave has its leaf [25], at the end of the network [26] and of the value-FC tile [27]
-#define PHASE_STAMP(k, cond) do { if (p.dbg_cycles && (cond)) p.dbg_cycles[(size_t)g * 32 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define PHASE_STAMP(k, cond) do { if constexpr (STAMPS) { if (p.dbg_cycles && (cond)) p.dbg_cycles[(size_t)g * 32 + (k)] = __builtin_amdgcn_s_memrealtime(); } } while (0)
     PHASE_STAMP(24, threadIdx.x == 0);
     // wave 0: the game's search, wave 1: its helper (encodes the leaf's planes while wave 0 generates the moves); both run
     // inside the tower's prologue (tower_body, Pre), after every wave has requested its first weights
@@ -154,6 +155,7 @@ __global__ __launch_bounds__(256, 1) void k_step(scnn::TowerArgs A, sc::SpParams
 
 namespace scl {
 #define K_STEP(P, C, RS, TPI, AB) scstep::k_step<scnn::P, C, RS, TPI, AB>
+#define K_STEP_STAMPED scstep::k_step<scnn::PrecBF16, 128, SC_T32_RS, SC_T32_TPI, SC_T32_AB, true>
 const char* step_init() {
     const void* kn[4] = {reinterpret_cast<const void*>(&K_STEP(PrecBF16, 128, SC_T32_RS, SC_T32_TPI, SC_T32_AB)),
                          reinterpret_cast<const void*>(&K_STEP(PrecBF16, 256, SC_T32W_RS, SC_T32W_TPI, SC_T32_AB)),
@@ -161,6 +163,10 @@ const char* step_init() {
                          reinterpret_cast<const void*>(&K_STEP(PrecFP8, 256, SC_T8W_RS, SC_T8W_TPI, SC_T8W_AB))};
     for (int i = 0; i < 4; i++) {
         hipError_t e = hipFuncSetAttribute(kn[i], hipFuncAttributeMaxDynamicSharedMemorySize, scnn::tower32_lds_bytes(i & 1 ? 256 : 128, i >= 2 && i < 4));
+        if (e != hipSuccess) return hipGetErrorString(e);
+    }
+    {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&K_STEP_STAMPED), hipFuncAttributeMaxDynamicSharedMemorySize, scnn::tower32_lds_bytes(128));
         if (e != hipSuccess) return hipGetErrorString(e);
     }
     return nullptr;
@@ -186,6 +192,8 @@ void step(const scnn::TowerArgs& a, const sc::SpParams& p, int do_expand, hipStr
         hipLaunchKernelGGL((K_STEP(PrecFP8, 128, SC_T8_RS, SC_T8_TPI, SC_T8_AB)), grid, block, scnn::tower32_lds_bytes(128, true), s, a, p, do_expand);
     else if (a.net.fp8)
         hipLaunchKernelGGL((K_STEP(PrecFP8, 256, SC_T8W_RS, SC_T8W_TPI, SC_T8W_AB)), grid, block, scnn::tower32_lds_bytes(256, true), s, a, p, do_expand);
+    else if (a.net.C == 128 && p.dbg_cycles)   // stamps switched on (sc_selfplay_debug_cycles): the stamped instantiation
+        hipLaunchKernelGGL((K_STEP_STAMPED), grid, block, scnn::tower32_lds_bytes(128), s, a, p, do_expand);
     else if (a.net.C == 128)
         hipLaunchKernelGGL((K_STEP(PrecBF16, 128, SC_T32_RS, SC_T32_TPI, SC_T32_AB)), grid, block, scnn::tower32_lds_bytes(128), s, a, p, do_expand);
     else
