@@ -301,9 +301,20 @@ constexpr int DEPTH_LDS = 1024;  // path entries tracked in LDS (a deeper path s
 #else
 #define SC_XSTAMP(k)
 #endif
-#define SC_STAMP(k)                                                                   \
-    do {                                                                              \
-        if (p.dbg_cycles && lane == 0) p.dbg_cycles[(size_t)g * 32 + (k)] = clock64(); \
+// Cycle stamps of the search's phases (tools/dbg_cycles.py).  Compiled into the kernel that runs every step they cost 0.7 % of
+// the headline even while switched off (same-box A/B, tools/ab_r02.py): SC_ST is a template argument of the functions that carry
+// them -- true in k_mcts and in the stamped instantiation of the fused step kernel, which the engine launches only while stamps are
+// switched on; experiment builds stamp everywhere.
+#ifdef SC_EXP
+#define SC_ST_DEFAULT true
+#else
+#define SC_ST_DEFAULT false
+#endif
+#define SC_STAMP(k)                                                                       \
+    do {                                                                                  \
+        if constexpr (SC_ST) {                                                            \
+            if (p.dbg_cycles && lane == 0) p.dbg_cycles[(size_t)g * 32 + (k)] = clock64(); \
+        }                                                                                 \
     } while (0)
 
 // Hand-off to a helper wavefront (fused step kernel): once the leaf position and its repetition flags stand, the plane
@@ -359,7 +370,7 @@ __device__ __forceinline__ void dev_encode_helper(const SpParams& p, int g, int 
 // Returns true when the selected leaf needs a network evaluation (planes, legal moves and action indices are then in
 // place).  PLANES_TO_HBM = false: the planes stay in s_stage (fused step kernel).  box != nullptr: the planes are encoded
 // by the helper wave (above) instead of this one.
-template <bool PLANES_TO_HBM = true>
+template <bool PLANES_TO_HBM = true, bool SC_ST = true>
 __device__ __forceinline__ bool dev_select(const SpParams& p, int g, int lane, int8_t* s_stage, move_t* s_moves, Position* s_leaf_p,
                                         uint16_t* s_ps, Position* s_hist, const GameCtl& cs_pre, bool cs_pre_valid,
                                         HelperBox* box = nullptr) {
@@ -861,6 +872,7 @@ __device__ __forceinline__ float value_tail_finish(const SpParams& p, const Valu
 
 // cs_out / cs_valid: the control block as this function leaves it, handed to dev_select in registers (a reload would be
 // a load of words stored a few instructions earlier); not valid after a ply transition
+template <bool SC_ST = true>
 __device__ __forceinline__ void dev_expand(SpParams& p, int g, int lane, Position* s_np_p, GameCtl& cs_out, bool& cs_valid) {
 #pragma clang fp contract(off)
     Position& s_np = *s_np_p;
@@ -1143,6 +1155,7 @@ __global__ __launch_bounds__(64) void k_mcts(SpParams p, int do_expand, int do_s
     __shared__ Position s_pos;
     __shared__ Position s_hist[8];
     __shared__ uint16_t s_ps[DEPTH_LDS];
+    constexpr bool SC_ST = true;   // (k_mcts runs the flush, the timed samples and the synthetic evaluators: never the hot loop)
     SC_STAMP(0);
     GameCtl cs_pre{};
     bool cs_pre_valid = false;

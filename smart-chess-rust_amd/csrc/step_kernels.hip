@@ -131,15 +131,16 @@ __global__ __launch_bounds__(256, 1) void k_step(scnn::TowerArgs A, sc::SpParams
             sc::dev_encode_helper(p, g, lane, &s_box, s_stage, &s_pos, s_ps, s_hist);
             return true;
         }
+        constexpr bool SC_ST = STAMPS || SC_ST_DEFAULT;
         SC_STAMP(0);
         sc::GameCtl cs_pre{};
         bool cs_pre_valid = false;
         if (do_expand) {
-            sc::dev_expand(p, g, lane, &s_pos, cs_pre, cs_pre_valid);
+            sc::dev_expand<SC_ST>(p, g, lane, &s_pos, cs_pre, cs_pre_valid);
             __builtin_amdgcn_wave_barrier();
         }
         SC_STAMP(1);
-        const bool need_net = sc::dev_select<false>(p, g, lane, s_stage, s_moves, &s_pos, s_ps, s_hist, cs_pre, cs_pre_valid, &s_box);
+        const bool need_net = sc::dev_select<false, SC_ST>(p, g, lane, s_stage, s_moves, &s_pos, s_ps, s_hist, cs_pre, cs_pre_valid, &s_box);
         PHASE_STAMP(25, lane == 0);
         return need_net;
     };
