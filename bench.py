@@ -287,20 +287,21 @@ def encode_steps_rate(scamd, eng, device):
 
 
 def match_rate(scamd, blocks, C, device):
-    """SURVEY.md 8f rank 2 (`play`, reference src/play.rs:318-343; scripts/leader-board): 100 games between two 10x128 networks,
-    one colour assignment, rollout 100, noise off, outcome after every ply, at most 200 plies"""
+    """SURVEY.md 8f rank 2 (`play`, reference src/play.rs:318-343; scripts/leader-board:44-54): 2 x 100 games between two 10x128 networks
+    -- both colour assignments, played at the same time on two streams -- rollout 100, noise off, outcome after every ply, <= 200 plies"""
     a, b = scamd.Engine(blocks, C, seed=1, device=device), scamd.Engine(blocks, C, seed=2, device=device)
     t0 = time.perf_counter()
-    r = scamd.play_match(a, b, n_games=100, rollout=100, cpuct=1.5, temperature=0.0, temperature_switch=0, num_steps=200, seed=3, swap=False)
+    r = scamd.play_match(a, b, n_games=100, rollout=100, cpuct=1.5, temperature=0.0, temperature_switch=0, num_steps=200, seed=3, swap=True)
     wall = time.perf_counter() - t0
-    res = r["as_white"]["results"]
-    plies = sum(len(t["steps"]) for t in r["as_white"]["traces"] if t)
+    plies = sum(len(t["steps"]) for k in ("as_white", "as_black") for t in r[k]["traces"] if t)
     a.close()
     b.close()
-    return {"games": 100, "rollout": 100, "nets": f"two {blocks}x{C} bf16 (seeds 1, 2)", "wall_s": round(wall, 3), "games_per_s": round(100 / wall, 2),
-            "plies": plies, "simulations_per_s": round(plies * 100 / wall, 1), "results": res,
-            "note": "all 100 games of one colour assignment in lockstep on one handle (sc_selfplay_set_players); games end at different "
-                    "plies, so late plies run with few live games"}
+    return {"games": 200, "rollout": 100, "nets": f"two {blocks}x{C} bf16 (seeds 1, 2)", "wall_s": round(wall, 3), "games_per_s": round(200 / wall, 2),
+            "plies": plies, "simulations_per_s": round(plies * 100 / wall, 1), "results_as_white": r["as_white"]["results"],
+            "results_as_black": r["as_black"]["results"], "elo_a_minus_b": r["elo_a_minus_b"] if abs(r["elo_a_minus_b"]) != float("inf") else None,
+            "note": "the reference's leader-board match: 100 games per colour assignment, each assignment in lockstep on its own handle and "
+                    "stream (sc_selfplay_set_players), the two running side by side; games end at different plies, so late plies run with few "
+                    "live games"}
 
 
 def sharp_prior_engine(scamd, n_blocks, C, device, precision):

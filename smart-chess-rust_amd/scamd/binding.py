@@ -404,6 +404,10 @@ def play_match(a, b, n_games=100, rollout=100, cpuct=1.5, temperature=0.0, tempe
     ply, at most 200 plies, random tie-break).  -> dict(results per colour assignment, a's score, Elo of a over b)."""
     out = {"as_white": None, "as_black": None}
     tot = win = lost = 0
+    # Both colour assignments play at the same time: each handle launches on the stream of its White engine, so the two sets of
+    # n_games workgroups share the GPU (100 + 100 of 256 CUs for the reference's 100-game matches) instead of running one after the
+    # other.  A game depends only on its seed and id: the results are those of the sequential loop.
+    handles = []
     for key, (w, bl) in (("as_white", (a, b)), ("as_black", (b, a))):
         if key == "as_black" and not swap:
             break
@@ -411,7 +415,16 @@ def play_match(a, b, n_games=100, rollout=100, cpuct=1.5, temperature=0.0, tempe
                       temperature=temperature, temperature_switch=temperature_switch, with_noise=False, outcome_gate=-1,
                       seed=seed + (0 if key == "as_white" else 1), tie_random=True)
         sp.set_players(w, bl)
-        sp.run()
+        handles.append((key, sp))
+    live = [sp for _, sp in handles]
+    while live:
+        for _ in range(2):                       # two plies per look at the statistics
+            if len(live) > 1:
+                enqueue_interleaved(live, rollout)
+            else:
+                live[0].enqueue(rollout)
+        live = [sp for sp in live if sp.stats()["games_active"] > 0]
+    for key, sp in handles:
         res = {"White": 0, "Black": 0, "draw": 0, "unfinished": 0}
         traces = []
         for g in range(n_games):
