@@ -1315,30 +1315,55 @@ __global__ __launch_bounds__(64) void k_replay_games(int n_games, const uint16_t
                                                      int hist_cap) {
     const int g = blockIdx.x, lane = threadIdx.x;
     if (g >= n_games) return;
-    __shared__ Position s_np;
+    // The walk is a chain of dependent steps on ONE wave: nothing in it may wait for global memory.  The repetition scan looks at the
+    // keys and irreversibility flags of the earlier plies of the line: they are kept in LDS (4.5 KB for 512 plies; longer games
+    // fall back to the records in global memory for the older part), the 80-byte records go out as plain stores nobody waits for.
+    constexpr int LDS_PLIES = 512;
+    __shared__ bb_t s_key[LDS_PLIES];
+    __shared__ uint8_t s_flags[LDS_PLIES];
+    struct KF {
+        bb_t key;
+        uint8_t flags;
+    };
+    struct LineChain {
+        const bb_t* key;
+        const uint8_t* flags;
+        const Position* hist;
+        __device__ KF pos(int i) const { return i < LDS_PLIES ? KF{key[i], flags[i]} : KF{hist[i].key, hist[i].flags}; }
+    };
     Position* hist = hist_all + (size_t)g * hist_cap;
     const uint16_t* mv = moves + move_off[g];
     const int nm = (int)(move_off[g + 1] - move_off[g]);
     Position cur;
     set_startpos(cur);
     cur.key = position_key(cur);
-    if (lane == 0) hist[0] = cur;
-    __syncthreads();
+    if (lane == 0) {
+        hist[0] = cur;
+        s_key[0] = cur.key;
+        s_flags[0] = cur.flags;
+    }
+    wave_sync();
+    const LineChain ch{s_key, s_flags, hist};
+    int mv64 = 0;   // the next 64 moves of the game, one per lane: one load per 64 plies instead of a dependent load per ply
     for (int i = 0; i < nm && i + 1 < hist_cap; i++) {
-        const move_t m = mv[i];
+        if ((i & 63) == 0) mv64 = (i + lane < nm) ? (int)mv[i + lane] : 0;
+        const move_t m = (move_t)__builtin_amdgcn_readlane(mv64, i & 63);
         const int from = mv_from(m), to = mv_to(m), promo = mv_promo(m);
         const bool ours = (occ_c(cur, cur.turn) & bit(from)) != 0, own_target = (occ_c(cur, cur.turn) & bit(to)) != 0;
         const bool promo_ok = promo == 0 || (promo >= 2 && promo <= 5 && (cur.pcs[PAWN] & bit(from)) != 0);
         if (ours && !own_target && promo_ok && from != to) make_move(cur, m);
-        if (lane == 0) s_np = cur;
-        __syncthreads();
-        DevChain ch{hist, i, hist, nullptr, &s_np, i + 1};
-        uint8_t rf = rep_flags_wave(ch, i + 1, cur.key, lane);
+        if (lane == 0 && i + 1 < LDS_PLIES) {
+            s_key[i + 1] = cur.key;
+            s_flags[i + 1] = cur.flags;          // (F_IRREV of the move that led here: what the scan stops at)
+        }
+        if (i + 1 >= LDS_PLIES) {                // very long games: the scan reads this ply's record from global memory
+            if (lane == 0) hist[i + 1] = cur;
+            __threadfence_block();
+        }
+        wave_sync();
+        const uint8_t rf = (uint8_t)__builtin_amdgcn_readfirstlane((int)rep_flags_wave(ch, i + 1, cur.key, lane));
         cur.flags = (uint8_t)((cur.flags & F_IRREV) | rf);
-        __syncthreads();
-        if (lane == 0) hist[i + 1] = cur;
-        __threadfence_block();
-        __syncthreads();
+        if (lane == 0) hist[i + 1] = cur;        // flags included; nobody in this kernel reads it back (k_encode_plies does)
     }
 }
 

@@ -522,6 +522,35 @@ def test_single_call_search(scamd, orc):
 
 
 @pytest.mark.gpu
+def test_encode_steps_very_long_game(scamd, orc):
+    """a 700-ply game of knight shuffles (every position repeats: both repetition planes set, the scan's window grows until the
+    75-move counter's irreversibility never comes) next to a short one: the game walk keeps the keys of the first 512 plies in LDS and
+    reads older... later ones from the records in global memory -- both paths against the oracle"""
+    cyc = ["g1f3", "g8f6", "f3g1", "f6g8", "b1c3", "b8c6", "c3b1", "c6b8"]
+    long_moves = [cyc[i % 8] for i in range(700)]
+    games = []
+    for moves in (long_moves, ["e2e4", "e7e5", "g1f3"]):
+        st = orc.State()
+        steps = []
+        for m in moves:
+            steps.append((m, [(orc.uci(x), 1 + (k % 3)) for k, x in enumerate(st.legal_moves())]))
+            st.push(m)
+        games.append(steps)
+    r = scamd.encode_steps_batch(games)
+    assert list(r["status"]) == [0, 0]
+    off = 0
+    for steps in games:
+        rc, ob, om, od, oi = orc.encode_steps(steps)
+        assert rc == 0
+        n = len(steps)
+        assert np.array_equal(r["boards"][off:off + n], ob) and np.array_equal(r["meta"][off:off + n], om)
+        assert np.array_equal(r["dist"][off:off + n].view(np.uint32), od.view(np.uint32))
+        assert all(np.array_equal(a, b) for a, b in zip(r["move_indices"][off:off + n], oi))
+        off += n
+    assert r["boards"][600][:, :, 12].any() and r["boards"][600][:, :, 13].any()      # is_repetition(2) and (3) planes late in the long game
+
+
+@pytest.mark.gpu
 def test_encode_steps_chunking(scamd, orc):
     """more plies than one launch holds (8192 per chunk): every chunk boundary falls inside a game and the result still
     equals the oracle (checked on a sample of games); games of very different lengths share the batch"""
