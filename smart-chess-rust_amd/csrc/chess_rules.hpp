@@ -323,6 +323,54 @@ SC_HD void make_move(Position& p, move_t m) {
     p.key = key ^ state_key(them, p.castling, has_legal_ep(p) ? p.ep : -1);
 }
 
+// The board half of make_move alone: pieces, occupancy, castling rights, ep square, clocks, side to move.  key and flags are left
+// zero: the training-tensor encoder walks a game with this (one wave per game, a chain of dependent steps) and computes the keys,
+// the irreversibility flag and the repetition flags of all plies in parallel afterwards (mcts_kernels.hpp: k_replay_raw,
+// k_ply_keys, k_ply_rep).  Must stay in step with make_move above (tests/test_gpu_parity.py::test_encode_steps_* compare the result
+// with the oracle).
+SC_HD void make_move_board(Position& p, move_t m) {
+    int from = mv_from(m), to = mv_to(m), promo = mv_promo(m);
+    int us = p.turn, them = !us;
+    bool zero = is_zeroing(p, m);
+    int old_ep = p.ep;
+    p.ep = -1;
+    p.halfmove = zero ? 0 : (uint16_t)(p.halfmove + 1);
+    if (us == BLACK) p.fullmove++;
+    bb_t fb = bit(from), tb = bit(to);
+    int pt = piece_type_at(p, from);
+    int cap = (occ_c(p, them) & tb) ? piece_type_at(p, to) : -1;
+    xor_pcs(p, pt, fb);
+    xor_occ(p, us, fb);
+    p.castling &= (uint8_t)~(castle_bit_for_sq(from) | castle_bit_for_sq(to));
+    if (pt == KING) p.castling &= us ? (uint8_t)~3 : (uint8_t)~12;
+    if (cap >= 0) {
+        xor_pcs(p, cap, tb);
+        xor_occ(p, them, tb);
+    }
+    if (pt == PAWN) {
+        int diff = to - from;
+        if (diff == 16 && (from >> 3) == 1) p.ep = (int8_t)(from + 8);
+        else if (diff == -16 && (from >> 3) == 6) p.ep = (int8_t)(from - 8);
+        else if (to == old_ep && (diff == 7 || diff == 9 || diff == -7 || diff == -9) && cap < 0) {
+            bb_t cb = bit(old_ep + (us ? -8 : 8));
+            p.pcs[PAWN] ^= cb;
+            xor_occ(p, them, cb);
+        }
+    }
+    int placed = promo ? promo - 1 : pt;
+    if (pt == KING && (to - from == 2 || from - to == 2)) {
+        int base = from & 56;
+        bb_t rf = bit(to > from ? base + 7 : base + 0), rt = bit(to > from ? base + 5 : base + 3);
+        p.pcs[ROOK] ^= rf | rt;
+        xor_occ(p, us, rf | rt);
+    }
+    xor_pcs(p, placed, tb);
+    xor_occ(p, us, tb);
+    p.turn = (uint8_t)them;
+    p.flags = 0;
+    p.key = 0;
+}
+
 // ------------------------------------------------------------------ legal move generation
 // python-chess _slider_blockers(king)
 SC_HD bb_t slider_blockers(const Position& p, int king) {

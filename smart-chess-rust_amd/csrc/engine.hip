@@ -485,8 +485,8 @@ int sc_encode_steps(sc_engine* e, int device_id, int n_games, const uint16_t* mo
     HIPOK(dalloc(&d_cmv, (size_t)nchild + 1));
     HIPOK(dalloc(&d_cn, (size_t)nchild + 1));
     HIPOK(dalloc(&d_coff, (size_t)cap + 1));
-    HIPOK(dalloc(&d_start, cap));
-    HIPOK(dalloc(&d_len, cap));
+    HIPOK(dalloc(&d_start, total));   // (all plies: the key / repetition kernels run over the whole batch at once)
+    HIPOK(dalloc(&d_len, total));
     HIPOK(dalloc(&d_hist, (size_t)n_games * hist_cap));   // one 80-byte record per ply of every game (k_replay_games)
     HIPOK(dalloc(&d_moff, (size_t)n_games + 1));
     HIPOK(dalloc(&d_boards, (size_t)cap * 7168));
@@ -509,9 +509,12 @@ int sc_encode_steps(sc_engine* e, int device_id, int n_games, const uint16_t* mo
     HIPOK(hipEventCreate(&evk[0]));
     HIPOK(hipEventCreate(&evk[1]));
     float kernels_ms = 0.f;
-    // every game is walked once (make_move, key, repetition flags: one record per ply); the plies are encoded from the records
+    // every game is walked once (board updates only: one record per ply), keys and repetition flags of all plies follow in parallel;
+    // then the plies are encoded from the records, 8 192 at a time
+    HIPOK(hipMemcpy(d_start, pstart.data(), (size_t)total * 4, hipMemcpyHostToDevice));
+    HIPOK(hipMemcpy(d_len, plen.data(), (size_t)total * 4, hipMemcpyHostToDevice));
     HIPOK(hipEventRecord(evk[0], nullptr));
-    scl::replay_games(n_games, d_moves, d_moff, d_hist, hist_cap, nullptr);
+    scl::replay_games(n_games, (int)total, d_moves, d_moff, d_hist, hist_cap, d_start, d_len, nullptr);
     HIPOK(hipEventRecord(evk[1], nullptr));
     HIPOK(hipGetLastError());
     HIPOK(hipDeviceSynchronize());
@@ -520,10 +523,8 @@ int sc_encode_steps(sc_engine* e, int device_id, int n_games, const uint16_t* mo
         const uint32_t n = std::min(CH, total - p0);
         for (uint32_t i = 0; i <= n; i++) coff[i] = child_off[p0 + i];   // absolute offsets into d_cmv / d_cn
         HIPOK(hipMemcpy(d_coff, coff.data(), ((size_t)n + 1) * 4, hipMemcpyHostToDevice));
-        HIPOK(hipMemcpy(d_start, pstart.data() + p0, (size_t)n * 4, hipMemcpyHostToDevice));
-        HIPOK(hipMemcpy(d_len, plen.data() + p0, (size_t)n * 4, hipMemcpyHostToDevice));
         HIPOK(hipEventRecord(evk[0], nullptr));
-        scl::encode_plies((int)n, d_hist, d_start, d_len, d_boards, d_meta, d_lm, d_li, d_nl, nullptr);
+        scl::encode_plies((int)n, d_hist, d_start + p0, d_len + p0, d_boards, d_meta, d_lm, d_li, d_nl, nullptr);
         // the ply's own move is moves[start + len] = d_moves + p0 + i
         scl::steps_dist((int)n, d_lm, d_nl, d_moves + p0, d_cmv, d_cn, d_coff, apply_mirror, d_meta, d_dist, d_flags, nullptr);
         HIPOK(hipEventRecord(evk[1], nullptr));

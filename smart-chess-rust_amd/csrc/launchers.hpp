@@ -15,7 +15,9 @@ void set_position(const sc::SpParams& p, int slot, const uint16_t* d_moves, int 
 void encode_positions(int n_pos, const uint16_t* d_moves, const uint32_t* d_move_off, const uint32_t* d_move_len, sc::Position* d_hist,
                       int hist_cap, int8_t* boards, int32_t* meta, uint16_t* legal_mv, uint16_t* legal_idx, int32_t* n_legal,
                       int32_t* outcome, hipStream_t s);
-void replay_games(int n_games, const uint16_t* d_moves, const uint32_t* d_move_off, sc::Position* d_hist, int hist_cap, hipStream_t s);
+// (all plies of all games: d_hoff / d_plen = record offset of the ply's game and moves played before the ply; d_moves[q] = ply q's move)
+void replay_games(int n_games, int n_plies, const uint16_t* d_moves, const uint32_t* d_move_off, sc::Position* d_hist, int hist_cap,
+                  const uint32_t* d_hoff, const uint32_t* d_plen, hipStream_t s);
 void encode_plies(int n, const sc::Position* d_hist, const uint32_t* d_hoff, const uint32_t* d_plen, int8_t* boards, int32_t* meta,
                   uint16_t* legal_mv, uint16_t* legal_idx, int32_t* n_legal, hipStream_t s);
 void steps_dist(int n, const uint16_t* legal_mv, const int32_t* n_legal, const uint16_t* next_mv, const uint16_t* child_mv,

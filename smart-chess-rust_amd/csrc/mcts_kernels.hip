@@ -20,9 +20,12 @@ void encode_positions(int n_pos, const uint16_t* d_moves, const uint32_t* d_move
     hipLaunchKernelGGL(sc::k_encode_positions, dim3(n_pos), dim3(64), 0, s, n_pos, d_moves, d_move_off, d_move_len, d_hist, hist_cap,
                        boards, meta, legal_mv, legal_idx, n_legal, outcome);
 }
-void replay_games(int n_games, const uint16_t* d_moves, const uint32_t* d_move_off, sc::Position* d_hist, int hist_cap, hipStream_t s) {
-    if (n_games <= 0) return;
-    hipLaunchKernelGGL(sc::k_replay_games, dim3(n_games), dim3(64), 0, s, n_games, d_moves, d_move_off, d_hist, hist_cap);
+void replay_games(int n_games, int n_plies, const uint16_t* d_moves, const uint32_t* d_move_off, sc::Position* d_hist, int hist_cap,
+                  const uint32_t* d_hoff, const uint32_t* d_plen, hipStream_t s) {
+    if (n_games <= 0 || n_plies <= 0) return;
+    hipLaunchKernelGGL(sc::k_replay_raw, dim3(n_games), dim3(64), 0, s, n_games, d_moves, d_move_off, d_hist, hist_cap);
+    hipLaunchKernelGGL(sc::k_ply_keys, dim3(n_plies), dim3(64), 0, s, n_plies, d_hist, d_hoff, d_plen, d_moves);
+    hipLaunchKernelGGL(sc::k_ply_rep, dim3(n_plies), dim3(64), 0, s, n_plies, d_hist, d_hoff, d_plen);
 }
 void encode_plies(int n, const sc::Position* d_hist, const uint32_t* d_hoff, const uint32_t* d_plen, int8_t* boards, int32_t* meta,
                   uint16_t* legal_mv, uint16_t* legal_idx, int32_t* n_legal, hipStream_t s) {

@@ -1311,39 +1311,20 @@ __global__ __launch_bounds__(64) void k_encode_positions(int n_pos, const uint16
 // or on a non-pawn -- and leaves the position unchanged for those (the ply is then reported as illegal by the per-ply check,
 // and the game's later plies are unspecified, include/sc_engine.h).
 #ifndef SC_NO_KERNELS
-__global__ __launch_bounds__(64) void k_replay_games(int n_games, const uint16_t* moves, const uint32_t* move_off, Position* hist_all,
-                                                     int hist_cap) {
+__global__ __launch_bounds__(64) void k_replay_raw(int n_games, const uint16_t* moves, const uint32_t* move_off, Position* hist_all,
+                                                   int hist_cap) {
+    // the only sequential part: one wave per game, board updates only (make_move_board: ~10 % of what a full make_move + repetition
+    // scan per ply cost when this kernel did everything -- 1.9 us per ply, 194 us for 100-ply games)
     const int g = blockIdx.x, lane = threadIdx.x;
     if (g >= n_games) return;
-    // The walk is a chain of dependent steps on ONE wave: nothing in it may wait for global memory.  The repetition scan looks at the
-    // keys and irreversibility flags of the earlier plies of the line: they are kept in LDS (4.5 KB for 512 plies; longer games
-    // fall back to the records in global memory for the older part), the 80-byte records go out as plain stores nobody waits for.
-    constexpr int LDS_PLIES = 512;
-    __shared__ bb_t s_key[LDS_PLIES];
-    __shared__ uint8_t s_flags[LDS_PLIES];
-    struct KF {
-        bb_t key;
-        uint8_t flags;
-    };
-    struct LineChain {
-        const bb_t* key;
-        const uint8_t* flags;
-        const Position* hist;
-        __device__ KF pos(int i) const { return i < LDS_PLIES ? KF{key[i], flags[i]} : KF{hist[i].key, hist[i].flags}; }
-    };
     Position* hist = hist_all + (size_t)g * hist_cap;
     const uint16_t* mv = moves + move_off[g];
     const int nm = (int)(move_off[g + 1] - move_off[g]);
     Position cur;
     set_startpos(cur);
-    cur.key = position_key(cur);
-    if (lane == 0) {
-        hist[0] = cur;
-        s_key[0] = cur.key;
-        s_flags[0] = cur.flags;
-    }
-    wave_sync();
-    const LineChain ch{s_key, s_flags, hist};
+    cur.key = 0;
+    cur.flags = 0;
+    if (lane == 0) hist[0] = cur;
     int mv64 = 0;   // the next 64 moves of the game, one per lane: one load per 64 plies instead of a dependent load per ply
     for (int i = 0; i < nm && i + 1 < hist_cap; i++) {
         if ((i & 63) == 0) mv64 = (i + lane < nm) ? (int)mv[i + lane] : 0;
@@ -1351,20 +1332,56 @@ __global__ __launch_bounds__(64) void k_replay_games(int n_games, const uint16_t
         const int from = mv_from(m), to = mv_to(m), promo = mv_promo(m);
         const bool ours = (occ_c(cur, cur.turn) & bit(from)) != 0, own_target = (occ_c(cur, cur.turn) & bit(to)) != 0;
         const bool promo_ok = promo == 0 || (promo >= 2 && promo <= 5 && (cur.pcs[PAWN] & bit(from)) != 0);
-        if (ours && !own_target && promo_ok && from != to) make_move(cur, m);
-        if (lane == 0 && i + 1 < LDS_PLIES) {
-            s_key[i + 1] = cur.key;
-            s_flags[i + 1] = cur.flags;          // (F_IRREV of the move that led here: what the scan stops at)
-        }
-        if (i + 1 >= LDS_PLIES) {                // very long games: the scan reads this ply's record from global memory
-            if (lane == 0) hist[i + 1] = cur;
-            __threadfence_block();
-        }
-        wave_sync();
-        const uint8_t rf = (uint8_t)__builtin_amdgcn_readfirstlane((int)rep_flags_wave(ch, i + 1, cur.key, lane));
-        cur.flags = (uint8_t)((cur.flags & F_IRREV) | rf);
-        if (lane == 0) hist[i + 1] = cur;        // flags included; nobody in this kernel reads it back (k_encode_plies does)
+        if (ours && !own_target && promo_ok && from != to) make_move_board(cur, m);
+        if (lane == 0) hist[i + 1] = cur;
     }
+}
+
+// transposition key of a position, lane = square: the same value as position_key() (XOR of the per-(piece, square) keys and the
+// state key), a wave XOR instead of a 32-iteration scalar loop
+__device__ inline bb_t position_key_wave(const Position& p, int lane, bool ep_legal) {
+    bb_t h = 0;
+    if ((all_occ(p) >> lane) & 1) h = psq_key(piece_type_at(p, lane), (int)((p.occ[WHITE] >> lane) & 1), lane);
+    unsigned lo = (unsigned)h, hi = (unsigned)(h >> 32);
+    for (int o = 32; o > 0; o >>= 1) {
+        lo ^= (unsigned)__shfl_xor((int)lo, o, 64);
+        hi ^= (unsigned)__shfl_xor((int)hi, o, 64);
+    }
+    return (((bb_t)hi << 32) | lo) ^ state_key(p.turn, p.castling, ep_legal ? p.ep : -1);
+}
+
+// one wave per ply, after k_replay_raw: the record's key, and F_IRREV of the move that led to it (python-chess is_irreversible on
+// the position before: zeroing, castling rights reduced, or a legal en-passant capture was available)
+__global__ __launch_bounds__(64) void k_ply_keys(int n, Position* hist_all, const uint32_t* hoff, const uint32_t* plen, const uint16_t* ply_move) {
+    const int q = blockIdx.x, lane = threadIdx.x;
+    if (q >= n) return;
+    Position* hist = hist_all + hoff[q];
+    const int i = (int)plen[q];
+    const Position pos = uniform(hist[i]);
+    const bool epl = has_legal_ep(pos);
+    const bb_t key = position_key_wave(pos, lane, epl);
+    uint8_t fl = 0;
+    if (i > 0) {
+        const Position prev = uniform(hist[i - 1]);
+        const move_t m = (move_t)uniform((int)ply_move[q - 1]);   // the game's previous ply is the previous ply of the batch
+        fl = (is_zeroing(prev, m) || reduces_castling(prev, m) || has_legal_ep(prev)) ? F_IRREV : 0;
+    }
+    if (lane == 0) {
+        hist[i].key = key;
+        hist[i].flags = fl;
+    }
+}
+// ... and, with every key and F_IRREV in place, the repetition flags (planes 12 / 13): is_repetition(2) / is_repetition(3)
+__global__ __launch_bounds__(64) void k_ply_rep(int n, Position* hist_all, const uint32_t* hoff, const uint32_t* plen) {
+    const int q = blockIdx.x, lane = threadIdx.x;
+    if (q >= n) return;
+    Position* hist = hist_all + hoff[q];
+    const int i = (int)plen[q];
+    const HistChain ch{hist};
+    const bb_t key0 = uniform(hist[i].key);
+    const uint8_t rf = (uint8_t)__builtin_amdgcn_readfirstlane((int)rep_flags_wave(ch, i, key0, lane));
+    // (a byte store beside the F_IRREV bit other waves' scans read: that bit does not change here)
+    if (lane == 0 && rf) hist[i].flags = (uint8_t)((hist[i].flags & F_IRREV) | rf);
 }
 
 // one wave per ply: the position BEFORE the ply's move from the game's records -- legal moves (python-chess order), action
