@@ -279,9 +279,9 @@ def encode_steps_rate(scamd, eng, device):
             "kernels_ms": round(k_ms, 3), "python_wall_ms": round(wall * 1e3, 2), "kernels_plies_per_s": round(plies / (k_ms * 1e-3), 1),
             "bytes_written_per_ply": out_bytes // plies,
             "roofline": {"bound": "hbm", "achieved": round(out_bytes / (k_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(out_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "kernel": "k_replay_games + k_encode_plies + k_steps_dist",
+                         "frac": round(out_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "kernel": "k_replay_raw + k_ply_keys + k_ply_rep + k_encode_plies + k_steps_dist",
                          "note": "algorithmic bytes written (planes 7168 + meta 28 + dist 18688 + move indices 448 + count 4 per ply) / HIP-event "
-                                 "time of the three kernels"},
+                                 "time of the five kernels"},
             "pcie_share_of_call": round(1.0 - k_ms / call_ms, 4),
             "note": "host-pointer ABI: the call = H2D of the traces + kernels + D2H of the tensors (pageable host memory) + host bookkeeping"}
 

@@ -136,7 +136,7 @@ int sc_encode_steps(sc_engine* engine_or_null, int device_id, int n_games, const
                     int8_t* boards, int32_t* meta, float* dist, uint16_t* legal_idx, int32_t* n_legal, int32_t* status);
 
 /* measurement aid (bench.py also_encode_steps): the last sc_encode_steps call of the calling thread -- HIP-event time of its
- * kernels (k_encode_positions + k_steps_dist, all chunks) and wall time of the whole call including the PCIe copies */
+ * kernels (game walk, keys, repetition flags, planes + moves, dist: all chunks) and wall time of the whole call including the PCIe copies */
 int sc_encode_steps_last_timing(float* kernels_ms, float* total_ms);
 
 /* ------------------------------------------------------------------ self-play (L-search) */
