@@ -994,10 +994,11 @@ __device__ __forceinline__ bool tower_body(const TowerArgs& A, const int pos, co
     const float se = (s_red[4] * __expf(s_red[0] - mx) + s_red[5] * __expf(s_red[1] - mx)) +
                      (s_red[6] * __expf(s_red[2] - mx) + s_red[7] * __expf(s_red[3] - mx));
     const float lse = mx + __logf(se);
-    // (the fused step kernel never writes the 4672 log-probabilities and always wants the priors.  Saying so at compile time is worth
-    // +1.45 % / +0.9 % simulations/s in the fp8 instantiations and -0.45 % in the bf16 one -- same-box A/B, tools/ab_r02.py: the
-    // kernels sit at the edge of their register budgets and the compiler's choices move with every branch -- so only fp8 says it)
-    constexpr bool LEAN = FUSED && P::FP8;
+    // (Not specialised for the fused step kernel, which never writes the log-probabilities: saying so at compile time was worth +0.9...
+    // +1.45 % in the fp8 instantiations, but the softmax / gather code then compiled differently in k_step and in k_tower32 and the fp8
+    // priors of `predict` and of the search differed by a few ulps -- tests/test_gpu_netloop.py caught it.  Code that produces
+    // numbers must be the same in both kernels.)
+    constexpr bool LEAN = false;
     if (!LEAN && A.logp) {
         float* lp = A.logp + (size_t)pos * 4672;
 #pragma unroll

@@ -6,9 +6,9 @@
 #endif
 
 #ifndef SC_T32W_RS
-#define SC_T32W_RS 8    // wide trunk: 8-slot ring, one tap per loop iteration (RS 8/12 x TPI 1/3/9 all measured
-#define SC_T32W_TPI 1   // within 0.5 % of each other)
-#endif
+#define SC_T32W_RS 8    // wide trunk: 8-slot ring, all 9 taps of a conv unrolled.  Round 1 measured RS 8/12 x TPI 1/3/9 within 0.5 % of each
+#define SC_T32W_TPI 9   // other in the stand-alone tower; in the fused step kernel the same-box A/B of round 3 (tools/ab_r02.py, 10x256,
+#endif                  // 256 games) gives TPI 9 +3.0 % over TPI 1 (RS 8, 9, 12 alike; TPI 3 +0.2 %; RS 4 -13 %)
 
 // fp8 (e4m3) towers: k-steps of 64 (half as many, twice as long: the same bytes in flight need half the ring slots)
 #ifndef SC_T8_RS

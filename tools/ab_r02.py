@@ -7,6 +7,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
     os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
     L = C.CDLL(sys.argv[2])
     prec, games = int(sys.argv[3]), int(sys.argv[4])
+    CH = int(os.environ.get("SC_AB_CHANNELS", "128"))
     class NetConfig(C.Structure):
         _fields_ = [("n_res_blocks", C.c_int32), ("channels", C.c_int32), ("seed", C.c_uint64), ("precision", C.c_int32), ("reserved", C.c_int32)]
     class SpCfg(C.Structure):
@@ -17,7 +18,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
     class Stats(C.Structure):
         _fields_ = [("sims_done", C.c_int64), ("nn_evals", C.c_int64), ("games_finished", C.c_int32), ("games_active", C.c_int32), ("error_flags", C.c_int32), ("plies_done", C.c_int32)]
     eng, sp = C.c_void_p(), C.c_void_p()
-    nc = NetConfig(10, 128, 1, prec, 0)
+    nc = NetConfig(10, CH, 1, prec, 0)
     assert L.sc_engine_create(C.byref(nc), None, 0, C.byref(eng)) == 0
     cfg = SpCfg(games, 10 ** 7, 180, 150, 2.5, 0.0, 4, 0.15, 1, 100, 0, 0, 1234, 0, 4 * games, 0, 0, 0, 0.0)
     assert L.sc_selfplay_create(eng, 0, C.byref(cfg), C.byref(sp)) == 0
