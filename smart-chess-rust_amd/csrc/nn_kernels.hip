@@ -6,7 +6,7 @@
 #endif
 #include "tower_config.hpp"
 #define K_T32N scnn::k_tower32<scnn::PrecBF16, 128, SC_T32_RS, SC_T32_TPI>
-#define K_T32W scnn::k_tower32<scnn::PrecBF16, 256, SC_T32W_RS, SC_T32W_TPI>
+#define K_T32W scnn::k_tower32<scnn::PrecBF16, 256, SC_T32W_RS, SC_T32W_TPI, SC_T32W_AB>
 #define K_T8N scnn::k_tower32<scnn::PrecFP8, 128, SC_T8_RS, SC_T8_TPI, SC_T8_AB>
 #define K_T8W scnn::k_tower32<scnn::PrecFP8, 256, SC_T8W_RS, SC_T8W_TPI, SC_T8W_AB>
 

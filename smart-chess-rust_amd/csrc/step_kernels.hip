@@ -159,7 +159,7 @@ namespace scl {
 #define K_STEP_STAMPED scstep::k_step<scnn::PrecBF16, 128, SC_T32_RS, SC_T32_TPI, SC_T32_AB, true>
 const char* step_init() {
     const void* kn[4] = {reinterpret_cast<const void*>(&K_STEP(PrecBF16, 128, SC_T32_RS, SC_T32_TPI, SC_T32_AB)),
-                         reinterpret_cast<const void*>(&K_STEP(PrecBF16, 256, SC_T32W_RS, SC_T32W_TPI, SC_T32_AB)),
+                         reinterpret_cast<const void*>(&K_STEP(PrecBF16, 256, SC_T32W_RS, SC_T32W_TPI, SC_T32W_AB)),
                          reinterpret_cast<const void*>(&K_STEP(PrecFP8, 128, SC_T8_RS, SC_T8_TPI, SC_T8_AB)),
                          reinterpret_cast<const void*>(&K_STEP(PrecFP8, 256, SC_T8W_RS, SC_T8W_TPI, SC_T8W_AB))};
     for (int i = 0; i < 4; i++) {
@@ -184,7 +184,7 @@ int step_blocks_per_cu(const scnn::NetLayout& net) {
     else if (net.C == 128)
         e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, K_STEP(PrecBF16, 128, SC_T32_RS, SC_T32_TPI, SC_T32_AB), 256, scnn::tower32_lds_bytes(128));
     else
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, K_STEP(PrecBF16, 256, SC_T32W_RS, SC_T32W_TPI, SC_T32_AB), 256, scnn::tower32_lds_bytes(256));
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, K_STEP(PrecBF16, 256, SC_T32W_RS, SC_T32W_TPI, SC_T32W_AB), 256, scnn::tower32_lds_bytes(256));
     return e == hipSuccess && n > 0 ? n : 1;
 }
 void step(const scnn::TowerArgs& a, const sc::SpParams& p, int do_expand, hipStream_t s) {
@@ -198,6 +198,6 @@ void step(const scnn::TowerArgs& a, const sc::SpParams& p, int do_expand, hipStr
     else if (a.net.C == 128)
         hipLaunchKernelGGL((K_STEP(PrecBF16, 128, SC_T32_RS, SC_T32_TPI, SC_T32_AB)), grid, block, scnn::tower32_lds_bytes(128), s, a, p, do_expand);
     else
-        hipLaunchKernelGGL((K_STEP(PrecBF16, 256, SC_T32W_RS, SC_T32W_TPI, SC_T32_AB)), grid, block, scnn::tower32_lds_bytes(256), s, a, p, do_expand);
+        hipLaunchKernelGGL((K_STEP(PrecBF16, 256, SC_T32W_RS, SC_T32W_TPI, SC_T32W_AB)), grid, block, scnn::tower32_lds_bytes(256), s, a, p, do_expand);
 }
 }  // namespace scl

@@ -10,6 +10,10 @@
 #define SC_T32W_TPI 9   // other in the stand-alone tower; in the fused step kernel the same-box A/B of round 3 (tools/ab_r02.py, 10x256,
 #endif                  // 256 games) gives TPI 9 +3.0 % over TPI 1 (RS 8, 9, 12 alike; TPI 3 +0.2 %; RS 4 -13 %)
 
+#ifndef SC_T32W_AB
+#define SC_T32W_AB 4   // image-fragment buffers of the wide trunk (SC_T32_AB, nn_tower32.hpp, for the narrow one)
+#endif
+
 // fp8 (e4m3) towers: k-steps of 64 (half as many, twice as long: the same bytes in flight need half the ring slots)
 #ifndef SC_T8_RS
 #define SC_T8_RS 6
