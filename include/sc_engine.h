@@ -263,8 +263,10 @@ int sc_selfplay_set_search(sc_selfplay*, float cpuct, float epsilon, int with_no
 /* One search as a single call: NNPlayer::bestmove's mcts::mcts (src/play.rs:241-252) / chess_play_mcts (src/lib.rs:233-247).
  * Runs `rollout` simulations from the position reached by `moves` (fresh tree, epsilon 0.15) and returns the number of root
  * children (< 0: error); child_move / child_n / child_q / child_prior receive up to `cap` of them in python-chess move
- * order (any may be NULL), *root_q the root's value sum.  For repeated searches keep a handle instead
- * (sc_selfplay_set_position + sc_selfplay_enqueue_sims + sc_selfplay_get_tree). */
+ * order (any may be NULL), *root_q the root's value sum.  The engine keeps ONE one-slot handle for these calls and reuses it
+ * (every call restarts from a one-node tree with its own options and seed: the result does not depend on earlier calls), so
+ * calls on one engine must not overlap; to keep the tree between moves use a handle of your own (sc_selfplay_set_position +
+ * sc_selfplay_enqueue_sims + sc_selfplay_get_tree). */
 int sc_search(sc_engine*, const uint16_t* moves, int n_moves, int rollout, float cpuct, int with_noise, uint64_t seed, int cap,
               uint16_t* child_move, int32_t* child_n, float* child_q, float* child_prior, float* root_q);
 

@@ -96,6 +96,10 @@ struct sc_engine {
     // scratch arena of sc_encode_positions (Level-1 callers encode one position per call: no malloc/free per call)
     void* d_enc = nullptr;
     size_t enc_cap = 0;
+    // the one-slot handle sc_search keeps between calls (NNPlayer::bestmove calls it once per move: building and freeing ~35 device
+    // buffers per call cost more than a short search) and the rollout its node pools are sized for
+    struct sc_selfplay* search_sp = nullptr;
+    int search_rollout_cap = 0;
 };
 
 static void engine_free_scratch(sc_engine* e) {
@@ -267,6 +271,10 @@ int sc_engine_create(const sc_net_config* cfg, const char* weights_path, int dev
 void sc_engine_destroy(sc_engine* e) {
     if (!e) return;
     (void)hipSetDevice(e->device);
+    if (e->search_sp) {
+        sc_selfplay_destroy(e->search_sp);
+        e->search_sp = nullptr;
+    }
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     engine_free_scratch(e);
     dfree({e->d_wb});
@@ -1376,19 +1384,42 @@ int sc_selfplay_set_search(sc_selfplay* sp, float cpuct, float epsilon, int with
 int sc_search(sc_engine* e, const uint16_t* moves, int n_moves, int rollout, float cpuct, int with_noise, uint64_t seed,
               int cap, uint16_t* child_move, int32_t* child_n, float* child_q, float* child_prior, float* root_q) {
     if (!e || rollout < 1 || rollout >= 60000 || cap < 0) return fail("bad argument");
-    sc_selfplay_config c{};
-    c.n_slots = 1;
-    c.n_games = 1;
-    c.rollout_num = rollout + 1;   // sizes the node pool; one more than the call runs, so no ply transition happens
-    c.num_steps = 4000;
-    c.cpuct = cpuct;
-    c.epsilon = 0.15f;         // mcts::mcts(.., 0.15, noise) at both call sites
-    c.with_noise = with_noise ? 1 : 0;
-    c.outcome_gate = 1 << 30;
-    c.evaluator = SC_EVAL_NET;
-    c.seed = seed;
-    sc_selfplay* sp = nullptr;
-    int rc = sc_selfplay_create(e, e->device, &c, &sp);
+    // one cached handle per engine, rebuilt only when a call asks for more simulations than its node pools hold; every call starts
+    // from a fresh one-node tree (sc_selfplay_set_position) with its own options and seed, so the result is that of a new handle
+    int rc = 0;
+    if (e->search_sp && (rollout + 1 > e->search_rollout_cap || e->search_sp->poisoned)) {
+        sc_selfplay_destroy(e->search_sp);
+        e->search_sp = nullptr;
+    }
+    if (!e->search_sp) {
+        sc_selfplay_config c{};
+        c.n_slots = 1;
+        c.n_games = 1;
+        c.rollout_num = std::max(rollout + 1, 512);   // sizes the node pool; more than any call runs, so no ply transition happens
+        c.num_steps = 4000;
+        c.cpuct = cpuct;
+        c.epsilon = 0.15f;         // mcts::mcts(.., 0.15, noise) at both call sites
+        c.with_noise = with_noise ? 1 : 0;
+        c.outcome_gate = 1 << 30;
+        c.evaluator = SC_EVAL_NET;
+        c.seed = seed;
+        rc = sc_selfplay_create(e, e->device, &c, &e->search_sp);
+        if (rc) {
+            e->search_sp = nullptr;
+            return rc;
+        }
+        e->search_rollout_cap = c.rollout_num;
+    }
+    sc_selfplay* sp = e->search_sp;
+    HIPOK(hipSetDevice(e->device));
+    HIPOK(hipStreamSynchronize(sp->stream));
+    sp->p.seed = seed;
+    sp->cfg.seed = seed;
+    rc = sc_selfplay_set_search(sp, cpuct, 0.15f, with_noise);
+    {   // an earlier call's error flags are not this call's
+        const int32_t zero = 0;
+        HIPOK(hipMemcpy(reinterpret_cast<char*>(sp->p.cnt) + offsetof(sc::Counters, err), &zero, 4, hipMemcpyHostToDevice));
+    }
     if (rc) return rc;
     rc = sc_selfplay_set_position(sp, 0, moves, n_moves);
     if (!rc) rc = sc_selfplay_enqueue_sims(sp, rollout);
@@ -1414,7 +1445,6 @@ int sc_search(sc_engine* e, const uint16_t* moves, int n_moves, int rollout, flo
             }
         }
     }
-    sc_selfplay_destroy(sp);
     return rc ? rc : n_children;
 }
 

@@ -522,6 +522,23 @@ def test_single_call_search(scamd, orc):
 
 
 @pytest.mark.gpu
+def test_single_call_search_reuses_its_handle(scamd, orc):
+    """sc_search keeps one handle per engine between calls: a call's result must not depend on the calls before it (other
+    positions, noise, seeds, a longer search that grows the cached node pool) -- each equals the first call of a fresh engine"""
+    calls = [(["d2d4", "g8f6", "c2c4"], 40, False, 0), (["e2e4"], 90, True, 7), ([], 24, False, 0), (["e2e4"], 90, True, 8),
+             (["e2e4", "e7e5", "g1f3", "b8c6"], 600, False, 3), (["d2d4", "g8f6", "c2c4"], 40, False, 0), (["e2e4"], 90, True, 7)]
+    eng = scamd.Engine(2, 128, seed=6)
+    got = [scamd.search(eng, line, n, cpuct=1.5, noise=noise, seed=seed) for line, n, noise, seed in calls]
+    eng.close()
+    assert got[0] == got[5] and got[1] == got[6] and got[1] != got[3]
+    for (line, n, noise, seed), g in zip(calls[:5], got):
+        fresh = scamd.Engine(2, 128, seed=6)
+        assert scamd.search(fresh, line, n, cpuct=1.5, noise=noise, seed=seed) == g
+        fresh.close()
+        assert sum(c[1] for c in g[1]) == n - 1
+
+
+@pytest.mark.gpu
 def test_encode_steps_very_long_game(scamd, orc):
     """a 700-ply game of knight shuffles (every position repeats: both repetition planes set, the scan's window grows until the
     75-move counter's irreversibility never comes) next to a short one: the game walk keeps the keys of the first 512 plies in LDS and
