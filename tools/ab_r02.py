@@ -5,6 +5,10 @@ import ctypes as C, os, sys, time, subprocess, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if len(sys.argv) > 1 and sys.argv[1] == "--child":
     os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+    if "@" in sys.argv[2]:   # lib@VAR=value[,VAR=value]: environment of this child (A/B of a runtime switch within one build)
+        sys.argv[2], envs = sys.argv[2].split("@", 1)
+        for kv in envs.split(","):
+            os.environ[kv.split("=")[0]] = kv.split("=", 1)[1]
     L = C.CDLL(sys.argv[2])
     prec, games = int(sys.argv[3]), int(sys.argv[4])
     CH = int(os.environ.get("SC_AB_CHANNELS", "128"))
@@ -41,4 +45,5 @@ for prec, games in (((0, 256),) if os.environ.get("SC_AB_BF16_ONLY") else ((0, 2
             r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", lib, str(prec), str(games)], capture_output=True, text=True, timeout=300)
             line = [l for l in r.stdout.splitlines() if l.startswith("{")]
             d = json.loads(line[-1]) if line else {"median_sims_per_s": 0, "err": r.stderr[-300:]}
-            print(f"{'fp8' if prec else 'bf16'} {games} games  {os.path.basename(os.path.dirname(lib)):8s} {d['median_sims_per_s'] / 1e6:.4f} M sims/s  err {d['err']}", flush=True)
+            tag = os.path.basename(os.path.dirname(lib.split("@")[0])) + ("@" + lib.split("@", 1)[1] if "@" in lib else "")
+            print(f"{'fp8' if prec else 'bf16'} {games} games  {tag:8s} {d['median_sims_per_s'] / 1e6:.4f} M sims/s  err {d['err']}", flush=True)
