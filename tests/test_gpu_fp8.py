@@ -92,6 +92,18 @@ def test_fp8_within_stated_tolerance_of_reference_goldens(scamd, orc, nb):
     eng.close()
 
 
+def test_fp8_10x128_within_stated_tolerance_of_reference_blocks(scamd):
+    """BASELINE configs[4]'s network at the width the fp8 bench lines use (10 x 128): the same claim against the vectors of the
+    128-wide network assembled from the reference's ResBlockSE / ValueHead classes (tools/gen_golden_nn.py)"""
+    g = np.load(os.path.join(GOLD, "nn_ref_b10_c128.npz"))
+    eng = scamd.Engine(10, 128, seed=int(g["seed"]), precision="fp8")
+    logp, val = eng.forward(g["boards"], g["meta"])
+    tv = _tv(logp, g["logp"])
+    print(f"fp8 10x128 vs reference blocks: max|dlogp|={np.abs(logp - g['logp']).max():.4f} max|dvalue|={np.abs(val - g['value']).max():.4f} max TVD={tv.max():.4f}")
+    assert tv.max() < 0.05 and np.abs(val - g["value"]).max() < 0.05
+    eng.close()
+
+
 def test_fp8_export_blob_equals_quantise_at_load(scamd, tmp_path):
     """three routes to the same fp8 engine, bit-identical outputs: the SCW2 export (tools/scw.py: e4m3 bytes + channel
     exponents), an fp32 SCW1 blob quantised at load (sc_net_config.precision), and the seeded init quantised at load"""

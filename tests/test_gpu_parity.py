@@ -83,6 +83,21 @@ def test_network_matches_reference_goldens(scamd, nb):
     eng.close()
 
 
+def test_network_matches_reference_blocks_at_128_channels(scamd):
+    """the headline's own trunk (10 x 128, BASELINE configs[1]) against vectors of a network assembled from the reference's ResBlockSE /
+    ValueHead classes at that width (tools/gen_golden_nn.py; the reference has no 128-wide ChessModule): the reference's rtol = atol = 1e-2
+    (scripts/eval_speed.py:40-43), priors within 1e-2 total variation (validate_inference.py:22-23)"""
+    g = np.load(os.path.join(GOLD, "nn_ref_b10_c128.npz"))
+    eng = scamd.Engine(10, 128, seed=int(g["seed"]))
+    logp, val = eng.forward(g["boards"], g["meta"])
+    tv = (0.5 * np.abs(np.exp(g["logp"].astype(np.float64)) - np.exp(logp.astype(np.float64))).sum(axis=1)).max()
+    print(f"10x128 vs reference blocks: max|dlogp| {np.abs(logp - g['logp']).max():.4f} max|dvalue| {np.abs(val - g['value']).max():.5f} max TV {tv:.5f}")
+    np.testing.assert_allclose(logp, g["logp"], rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(val, g["value"], rtol=RTOL, atol=ATOL)
+    assert tv < 1e-2
+    eng.close()
+
+
 @pytest.mark.parametrize("C,nb", [(128, 3), (256, 2), (128, 0), (256, 0), (128, 19)])
 def test_network_matches_bf16_emulating_oracle(scamd, orc, C, nb):
     """tight check (quantisation points identical, only summation order differs); covers the build-defined

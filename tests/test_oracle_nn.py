@@ -24,6 +24,19 @@ def test_oracle_matches_reference_module(orc, nb):
         assert abs(np.exp(logp.astype(np.float64)).sum() - 1) < 1e-5
 
 
+def test_oracle_matches_reference_blocks_at_128_channels(orc):
+    """BASELINE configs[1]'s 128-channel trunk: the reference's ChessModule is 256 wide only, but its ResBlockSE and ValueHead classes
+    take a width -- vectors from a network ASSEMBLED from those classes (tools/gen_golden_nn.py: stem and policy head written out from
+    the reference's layer lists with BASELINE's widths) pin the oracle's 128-channel mode to the reference's own block code"""
+    g = np.load(os.path.join(GOLD, "nn_ref_b10_c128.npz"))
+    assert int(g["n_params"]) == 5436252
+    net = orc.Net(10, 128, seed=int(g["seed"]))
+    for k in range(len(g["names"])):
+        logp, v = net.forward(g["boards"][k], g["meta"][k])
+        np.testing.assert_allclose(logp, g["logp"][k], rtol=0, atol=5e-5)
+        assert abs(v - g["value"][k]) < 5e-6
+
+
 def _sharp_state_dict(g):
     sd = scw.prng_state_dict(10, 256, int(g["seed"]))
     sd["policy_head.model.3.weight"] = sd["policy_head.model.3.weight"] * np.float32(g["policy_gain_scale"])

@@ -122,6 +122,59 @@ def main():
                             n_params=np.int64(sum(p.numel() for p in model.parameters())))
         print(n_blocks, "blocks:", logp.shape, value.reshape(-1)[:4], "params", sum(p.numel() for p in model.parameters()))
 
+    # BASELINE configs[1]'s 128-channel trunk has no instantiation in the reference (ChessModule hard-codes 256, py/module.py:120-133).
+    # Its building blocks do take a width: the network below is ASSEMBLED from the reference's own classes -- ResBlockSE(128, 128)
+    # (py/module.py:14-46: 20 of its 23 convs, both LayerNorms and the SE of every block) and ValueHead(128, "LayerNorm")
+    # (py/module.py:83-106) -- around a stem and a policy head written out layer by layer from the reference's lists with the widths
+    # BASELINE gives them (py/module.py:120-126 with 128 output channels; py/module.py:70-80 with its second conv taking the first
+    # one's 256 outputs: PolicyHead(din) itself only runs with din == 256), and ChessModule.forward's body (py/module.py:136-152).
+    path = os.path.join(out_dir, "nn_ref_b10_c128.npz")
+    if not os.path.exists(path) or "--force" in sys.argv:
+        n_blocks, C, seed = 10, 128, 20260701
+        LN = refmod.NormTable["LayerNorm"]
+
+        class NarrowPolicy(torch.nn.Module):
+            def __init__(self):
+                super().__init__()
+                self.model = torch.nn.Sequential(torch.nn.Conv2d(C, 256, kernel_size=1), LN(256), torch.nn.Conv2d(256, 73, kernel_size=1), LN(73),
+                                                 torch.nn.Flatten())
+
+            def forward(self, x):
+                return torch.nn.functional.log_softmax(self.model(x), dim=1)
+
+        class Narrow(torch.nn.Module):
+            def __init__(self):
+                super().__init__()
+                self.conv_block = torch.nn.Sequential(torch.nn.Conv2d(112, C, kernel_size=3, stride=1, padding=1), LN(C), torch.nn.ReLU())
+                self.res_blocks = torch.nn.ModuleList([refmod.ResBlockSE(C, C) for _ in range(n_blocks)])
+                self.value_head = refmod.ValueHead(C, norm="LayerNorm")
+                self.policy_head = NarrowPolicy()
+
+            def forward(self, inp, meta):
+                x = self.conv_block(inp)
+                for block in self.res_blocks:
+                    x = block(x)
+                v1 = self.policy_head(x)
+                v2 = self.value_head(x, meta) * (meta[:, 0].unsqueeze(-1) * 2 - 1)
+                return v1, v2
+
+        model = Narrow().eval()
+        table = scw.tensor_table(n_blocks, C)
+        sd = model.state_dict()
+        assert [k for k in sd.keys()] == [t[0] for t in table], "state_dict order differs from tools/scw.py"
+        for (name, shape, _, _) in table:
+            assert tuple(sd[name].shape) == tuple(shape), name
+        new = scw.prng_state_dict(n_blocks, C, seed=seed)
+        model.load_state_dict({k: torch.from_numpy(v) for k, v in new.items()}, strict=True)
+        inp = torch.from_numpy(boards.astype(np.float32)).permute(0, 3, 1, 2).contiguous()
+        meta = torch.from_numpy(metas.astype(np.float32))
+        with torch.no_grad():
+            logp, value = model(inp, meta)
+        np.savez_compressed(path, names=np.array(names), boards=boards, meta=metas, logp=logp.numpy().astype(np.float32),
+                            value=value.numpy().astype(np.float32).reshape(-1), seed=np.int64(seed),
+                            n_params=np.int64(sum(p.numel() for p in model.parameters())))
+        print("narrow 10 x 128:", logp.shape, value.reshape(-1)[:4], "params", sum(p.numel() for p in model.parameters()))
+
     # A trained network's outputs are not those of a U(-k, k) init: its log-probabilities reach magnitudes of 12-21
     # (reference notebooks/check_model.ipynb cells 6-8) and its value leaves the linear part of tanh.  Same PRNG weights with
     # the gain of the policy head's last LayerNorm x 4 and value_head.ffn.2.weight x 2: logits of that magnitude, through the
